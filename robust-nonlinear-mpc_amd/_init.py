@@ -1,0 +1,2 @@
+"""MI355X-native batched fast-SLS QP path.  Public names re-exported here."""
+from .models import ModelData, pendulum, quadrotor, rocket, get_model  # noqa: F401

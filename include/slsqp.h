@@ -1,0 +1,122 @@
+/*
+ * slsqp.h -- C ABI of the MI355X-native batched fast-SLS QP path (libslsqp_hip.so).
+ *
+ * Every entry point replaces a call the reference makes on its hot path (citations relative to the
+ * reference repository antoineleeman/robust-nonlinear-mpc):
+ *
+ *   slsqp_create / destroy          fast_SLS.__init__                 solver/fast_SLS_jit.py:202-241
+ *                                   (QP._assemble_structures + first OSQP setup, solver/qp_jit.py:77-192, 278-306)
+ *   slsqp_set_costs                 OCP.__init__ weights              solver/ocp.py:8-38; SCP_SLS_jit.py:386-388
+ *   slsqp_set_constraints           LTV(m,N) G,Gf,gf copies           dyn/LTV.py:17-32
+ *   slsqp_update_dynamics           fast_SLS.update_dynamics_list     solver/fast_SLS_jit.py:250-273
+ *                                   (QP.update_dynamics :518-576, offset_constraints :595-610)
+ *   slsqp_update_linear_cost        fast_SLS.update_linear_cost       solver/fast_SLS_jit.py:575-576
+ *   slsqp_solve                     fast_SLS.solve                    solver/fast_SLS_jit.py:278-312
+ *   slsqp_get                       post_processing_solution          solver/fast_SLS_jit.py:602-646
+ *   slsqp_reset                     reset_solver_to_zeros             solver/fast_SLS_jit.py:424-442
+ *   slsqp_qp_update_data_mat/_vec,  module `osqp_generated`           solver/qp_jit.py:671-698 (push), :449-470 (solve)
+ *   slsqp_qp_solve                  (update_data_mat / update_data_vec / solve)
+ *   slsqp_sweep                     backward_solve + update_tightening kernels  solver/fast_SLS_jit.py:489-571
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; all arrays are C-contiguous fp64 (int32 for status/iter).
+ *   - `loc` says where caller buffers live: SLSQP_HOST (library copies over PCIe) or SLSQP_DEVICE (device
+ *     pointers on the handle's GPU, consumed/produced in place on the handle's stream).
+ *   - the batch axis B (independent MPC instances) is always the leading axis.
+ *   - return value: 0 ok, <0 API misuse / unsupported configuration (message via slsqp_last_error()).
+ *     Per-instance outcomes never fail the call: see status[B] (SLSQP_ST_*).
+ *   - one handle = one GPU + one HIP stream; distinct handles may be used from distinct threads.
+ */
+#ifndef SLSQP_H
+#define SLSQP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slsqp_handle slsqp_handle;
+
+typedef struct {
+    int nx, nu, nw; /* state / input / disturbance dims */
+    int N;          /* horizon */
+    int ni, ni_f;   /* stage / terminal inequality rows; must be 2(nx+nu) and 2nx (G=[I;-I], Gf=[I;-I]) */
+} slsqp_dims;
+
+enum { SLSQP_HOST = 0, SLSQP_DEVICE = 1 };
+
+/* per-instance status */
+enum {
+    SLSQP_ST_SOLVED = 0,      /* KKT certificate met (polished active-set solution) */
+    SLSQP_ST_SOLVED_IPM = 4,  /* interior-point tolerance met, polish rejected (solution accurate to opts.eps) */
+    SLSQP_ST_MAX_ITER = 1,
+    SLSQP_ST_INFEASIBLE = 2,  /* primal infeasible (x0 pin outside its box, or divergence) */
+    SLSQP_ST_NUMERICAL = 3
+};
+
+typedef struct {
+    int rti_steps;       /* >0: RTI mode, exactly that many fast-SLS steps then one final QP (fast_SLS_jit.py:280-296);
+                            <=0: converge mode, up to max_sls_iter steps (:298-312) */
+    int max_sls_iter;    /* MAX_ITER (30, fast_SLS_jit.py:206) */
+    int qp_max_iter;     /* interior-point iteration cap per QP (default 60) */
+    double qp_eps;       /* interior-point residual / complementarity tolerance before polish (default 1e-8) */
+    double conv_tol;     /* primal convergence test of check_convergence_socp (1e-3, fast_SLS_jit.py:594) */
+    double eps_backoff;  /* epsilon_backoff (1e-10, fast_SLS_jit.py:205) */
+    int want_K;          /* also keep K (N,N+1,nu,nx) for slsqp_get */
+} slsqp_opts;
+
+void slsqp_default_opts(slsqp_opts *o);
+const char *slsqp_last_error(void);
+const char *slsqp_version(void);
+
+slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device);
+void slsqp_destroy(slsqp_handle *h);
+
+/* Q (nx,nx) R (nu,nu) Qf (nx,nx): must be diagonal (all reference scripts use np.diag); Q_reg/R_reg/Q_reg_f likewise.
+   Host pointers. Batch-constant. */
+int slsqp_set_costs(slsqp_handle *h, const double *Q, const double *R, const double *Qf, const double *Q_reg,
+                    const double *R_reg, const double *Q_reg_f);
+/* G (ni,nx+nu), Gf (ni_f,nx), gf (ni_f): host pointers; G,Gf must be [I;-I]. gf is the RAW terminal bound that the
+   tightened QP uses (fast_SLS_jit.py:524,568). */
+int slsqp_set_constraints(slsqp_handle *h, const double *G, const double *Gf, const double *gf);
+
+/* A (B,N,nx,nx)  Bm (B,N,nx,nu)  E (N+1,nx,nw) shared by the batch (NULL keeps the previous one)
+   g (B,N,ni) shifted stage bounds g_k = g - G [z_k;v_k];  g_N (B,ni_f) shifted terminal bound gf - Gf z_N
+   c (B,N,nx) dynamics offsets c_k = f(z_k,v_k) - z_{k+1}.
+   Effect = QP.update_dynamics + offset_constraints: ubg <- [-c_k + eps ; g_k + eps]..., g_N + eps ; lbg <- [-c_k - eps ; -inf]. */
+int slsqp_update_dynamics(slsqp_handle *h, const double *A, const double *Bm, const double *E, const double *g,
+                          const double *g_N, const double *c, int loc);
+int slsqp_update_linear_cost(slsqp_handle *h, const double *q, int loc); /* q (B,n) */
+
+/* x0 (B,nx): the argument of fast_SLS.solve, i.e. x_nom0 - x_meas.  Runs the whole fast-SLS iteration on the GPU. */
+int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts);
+
+/* Fetch a result array by name into `out` (host or device).  Names and shapes (B leading):
+   primal_vec (n) dual_vec (m-nx) cost_nominal (1) status[int32] (1) qp_iters[int32] (1) iteration_number[int32] (1)
+   beta (N,N,ni) beta_f (N+1,ni_f) backoff (N,ni) backoff_f (ni_f) backoff_x (N+1,nx) backoff_u (N,nu)
+   eta (N,N,ni) eta_f (N+1,ni_f) K (N,N+1,nu,nx) ubg (m-nx) lbg (m-nx) kkt (4) */
+int slsqp_get(slsqp_handle *h, const char *name, void *out, int loc);
+int slsqp_reset(slsqp_handle *h);
+int slsqp_sync(slsqp_handle *h);
+
+/* ---- QP-level boundary: mirrors the three calls of the reference's generated module ----------------------- */
+/* P_x (B,nnzP): CSC data of triu(2P) (diagonal => nnzP = n);  A_x (B,nnzA): CSC data of the (m x n) constraint
+   matrix INCLUDING the x0-pin rows, sorted indices, pattern of qp_jit.py:77-192 with G=[I;-I]. */
+int slsqp_qp_nnz(const slsqp_dims *d, int *n, int *m, int *nnzP, int *nnzA);
+int slsqp_qp_update_data_mat(slsqp_handle *h, const double *P_x, const double *A_x, int loc);
+int slsqp_qp_update_data_vec(slsqp_handle *h, const double *q, const double *l, const double *u, int loc); /* (B,n) (B,m) (B,m) */
+/* x (B,n), y (B,m) OSQP sign convention, status (B), iters (B) */
+int slsqp_qp_solve(slsqp_handle *h, double *x, double *y, int *status, int *iters, int loc, const slsqp_opts *opts);
+
+/* ---- sweep-level boundary ---------------------------------------------------------------------------------- */
+/* eta (B,N,N,ni) eta_f (B,N+1,ni_f) in; K/beta/beta_f/backoff/backoff_f out (any may be NULL). Uses the handle's A,B,E. */
+int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta_f, double *K, double *beta, double *beta_f,
+                double *backoff, double *backoff_f, int loc);
+
+/* elapsed GPU time (ms) of the kernels launched by the last slsqp_solve / slsqp_qp_solve / slsqp_sweep call,
+   measured with HIP events on the handle's stream: [0] total, [1] QP kernel(s), [2] sweep kernel, [3] other */
+int slsqp_last_timing(slsqp_handle *h, double *ms4);
+void *slsqp_stream(slsqp_handle *h); /* hipStream_t, for callers that share device buffers */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,519 @@
+// slsqp_api.hip -- C-ABI host side of libslsqp_hip.so (see include/slsqp.h for the contract and the reference
+// call sites each entry point replaces).  The fast-SLS control flow of fast_SLS.solve
+// (solver/fast_SLS_jit.py:278-327) is run here as a short sequence of batched kernel launches with
+// per-instance masks, so one infeasible or converged instance never stalls or fails the batch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/slsqp.h"
+#include "slsqp_kernels.hpp"
+
+using namespace slsqp;
+
+static thread_local std::string g_err;
+static int fail(const std::string &m) { g_err = m; return -1; }
+#define HIPCHK(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+extern "C" const char *slsqp_last_error(void) { return g_err.c_str(); }
+extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
+
+extern "C" void slsqp_default_opts(slsqp_opts *o) {
+    o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-8; o->conv_tol = 1e-3;
+    o->eps_backoff = 1e-10; o->want_K = 1;
+}
+
+struct slsqp_handle {
+    slsqp_dims d;
+    int B, dev, n, m, mb, nz;
+    hipStream_t st;
+    // problem data
+    double *A, *Bm, *E, *g, *gN, *c, *q, *x0val, *gf_raw, *cst;  // cst: Qd Rd Qfd Qregd Rregd Qregfd packed
+    double *ubg, *lbg;
+    // results / state
+    double *primal, *dual, *cost, *pin_dual, *kkt, *prev_primal, *Linv;
+    double *eta, *eta_f, *beta, *beta_f, *backoff, *backoff_f, *backoff_x, *backoff_u, *K;
+    int *status, *iters, *itnum, *has_prev, *conv, *alive, *mask, *success, *infeas, *counter;
+    // qp-level CSC maps
+    int *mapA, *mapB;  // CSC offsets of A_k[i][j] / B_k[i][j]
+    double *stage;     // staging buffer for host<->device transfers
+    size_t stage_bytes;
+    bool have_costs, have_cons, have_dyn;
+    hipEvent_t ev[8];
+    double t_total, t_qp, t_sweep;
+    std::map<std::string, std::pair<void *, size_t>> named;  // name -> (device ptr, bytes per instance)
+};
+
+static Costs costs_of(slsqp_handle *h) {
+    const int nx = h->d.nx, nu = h->d.nu;
+    Costs c;
+    c.Qd = h->cst; c.Rd = c.Qd + nx; c.Qfd = c.Rd + nu; c.Qregd = c.Qfd + nx; c.Rregd = c.Qregd + nx; c.Qregfd = c.Rregd + nu;
+    return c;
+}
+
+template <typename T>
+static int dalloc(T **p, size_t count) {
+    HIPCHK(hipMalloc((void **)p, count * sizeof(T) + 64));
+    HIPCHK(hipMemset(*p, 0, count * sizeof(T)));
+    return 0;
+}
+
+static bool supported_dims(int nx, int nu) { return (nx == 4 && nu == 1) || (nx == 13 && nu == 4) || (nx == 17 && nu == 4); }
+
+extern "C" int slsqp_qp_nnz(const slsqp_dims *d, int *n, int *m, int *nnzP, int *nnzA) {
+    const int nz = d->nx + d->nu;
+    *n = nz * d->N + d->nx;
+    *m = d->N * (d->nx + d->ni) + d->ni_f + d->nx;
+    *nnzP = *n;
+    *nnzA = d->N * (d->nx * (nz + 1) + 2 * nz) + 3 * d->nx;
+    return 0;
+}
+
+extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device) {
+    if (!supported_dims(d->nx, d->nu)) { fail("unsupported (nx,nu): kernels are instantiated for (4,1) (13,4) (17,4)"); return nullptr; }
+    if (d->ni != 2 * (d->nx + d->nu) || d->ni_f != 2 * d->nx) { fail("ni/ni_f must be 2(nx+nu)/2nx (box constraints G=[I;-I])"); return nullptr; }
+    if (d->nw != d->nx) { fail("nw must equal nx"); return nullptr; }
+    if (d->N < 1 || d->N > 32 || batch < 1) { fail("need 1 <= N <= 32 and batch >= 1"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fail("no HIP device visible: libslsqp_hip has no CPU fallback"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
+    slsqp_handle *h = new slsqp_handle();
+    h->d = *d; h->B = batch; h->dev = device;
+    const int nx = d->nx, nu = d->nu, N = d->N, ni = d->ni, nif = d->ni_f, nw = d->nw;
+    h->nz = nx + nu; h->n = h->nz * N + nx; h->mb = N * (nx + ni) + nif; h->m = h->mb + nx;
+    const size_t B = batch;
+    if (hipStreamCreate(&h->st) != hipSuccess) { fail("hipStreamCreate"); delete h; return nullptr; }
+    int rc = 0;
+    rc |= dalloc(&h->A, B * N * nx * nx); rc |= dalloc(&h->Bm, B * N * nx * nu); rc |= dalloc(&h->E, (size_t)(N + 1) * nx * nw);
+    rc |= dalloc(&h->g, B * N * ni); rc |= dalloc(&h->gN, B * nif); rc |= dalloc(&h->c, B * N * nx); rc |= dalloc(&h->q, B * h->n);
+    rc |= dalloc(&h->x0val, B * nx); rc |= dalloc(&h->gf_raw, (size_t)nif); rc |= dalloc(&h->cst, (size_t)(3 * nx + 2 * nu) * 2);
+    rc |= dalloc(&h->ubg, B * h->mb); rc |= dalloc(&h->lbg, B * h->mb);
+    rc |= dalloc(&h->primal, B * h->n); rc |= dalloc(&h->dual, B * h->mb); rc |= dalloc(&h->cost, B); rc |= dalloc(&h->pin_dual, B * nx);
+    rc |= dalloc(&h->kkt, B * 4); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx);
+    rc |= dalloc(&h->eta, B * N * N * ni); rc |= dalloc(&h->eta_f, B * (N + 1) * nif); rc |= dalloc(&h->beta, B * N * N * ni);
+    rc |= dalloc(&h->beta_f, B * (N + 1) * nif); rc |= dalloc(&h->backoff, B * N * ni); rc |= dalloc(&h->backoff_f, B * nif);
+    rc |= dalloc(&h->backoff_x, B * (N + 1) * nx); rc |= dalloc(&h->backoff_u, B * N * nu); rc |= dalloc(&h->K, B * N * (N + 1) * nu * nx);
+    rc |= dalloc(&h->status, B); rc |= dalloc(&h->iters, B); rc |= dalloc(&h->itnum, B); rc |= dalloc(&h->has_prev, B); rc |= dalloc(&h->conv, B);
+    rc |= dalloc(&h->alive, B); rc |= dalloc(&h->mask, B); rc |= dalloc(&h->success, B); rc |= dalloc(&h->infeas, B); rc |= dalloc(&h->counter, (size_t)4);
+    rc |= dalloc(&h->mapA, (size_t)N * nx * nx); rc |= dalloc(&h->mapB, (size_t)N * nx * nu);
+    if (rc) { delete h; return nullptr; }
+    for (auto &e : h->ev) hipEventCreate(&e);
+    // CSC offsets of the reference's frozen pattern (qp_jit.py:101-123,178-186; columns sorted by row)
+    {
+        std::vector<int> mA((size_t)N * nx * nx), mB((size_t)N * nx * nu);
+        int p = 0;
+        for (int k = 0; k <= N; k++) {
+            for (int j = 0; j < nx; j++) {      // column of x_k[j]
+                if (k >= 1) p += 1;              // -I entry in dynamics row block k-1
+                if (k < N) { for (int i = 0; i < nx; i++) mA[((size_t)k * nx + i) * nx + j] = p + i; p += nx; p += 2; }
+                else p += 2;                     // terminal +1 / -1
+                if (k == 0) p += 1;              // x0 pin row (last rows of the matrix)
+            }
+            if (k < N)
+                for (int a = 0; a < nu; a++) {   // column of u_k[a]
+                    for (int i = 0; i < nx; i++) mB[((size_t)k * nx + i) * nu + a] = p + i;
+                    p += nx; p += 2;
+                }
+        }
+        hipMemcpy(h->mapA, mA.data(), mA.size() * sizeof(int), hipMemcpyHostToDevice);
+        hipMemcpy(h->mapB, mB.data(), mB.size() * sizeof(int), hipMemcpyHostToDevice);
+    }
+    h->stage = nullptr; h->stage_bytes = 0;
+    h->have_costs = h->have_cons = h->have_dyn = false;
+    h->t_total = h->t_qp = h->t_sweep = 0;
+    auto reg = [&](const char *nm, void *p, size_t bytes) { h->named[nm] = {p, bytes}; };
+    reg("primal_vec", h->primal, sizeof(double) * h->n); reg("dual_vec", h->dual, sizeof(double) * h->mb); reg("cost_nominal", h->cost, sizeof(double));
+    reg("status", h->status, sizeof(int)); reg("qp_iters", h->iters, sizeof(int)); reg("iteration_number", h->itnum, sizeof(int));
+    reg("success", h->success, sizeof(int));
+    reg("beta", h->beta, sizeof(double) * N * N * ni); reg("beta_f", h->beta_f, sizeof(double) * (N + 1) * nif);
+    reg("backoff", h->backoff, sizeof(double) * N * ni); reg("backoff_f", h->backoff_f, sizeof(double) * nif);
+    reg("backoff_x", h->backoff_x, sizeof(double) * (N + 1) * nx); reg("backoff_u", h->backoff_u, sizeof(double) * N * nu);
+    reg("eta", h->eta, sizeof(double) * N * N * ni); reg("eta_f", h->eta_f, sizeof(double) * (N + 1) * nif);
+    reg("K", h->K, sizeof(double) * N * (N + 1) * nu * nx); reg("ubg", h->ubg, sizeof(double) * h->mb); reg("lbg", h->lbg, sizeof(double) * h->mb);
+    reg("kkt", h->kkt, sizeof(double) * 4); reg("pin_dual", h->pin_dual, sizeof(double) * nx);
+    return h;
+}
+
+extern "C" void slsqp_destroy(slsqp_handle *h) {
+    if (!h) return;
+    hipSetDevice(h->dev);
+    hipStreamSynchronize(h->st);
+    void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
+                    h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
+                    h->backoff_u, h->K, h->status, h->iters, h->itnum, h->has_prev, h->conv, h->alive, h->mask, h->success, h->infeas,
+                    h->counter, h->mapA, h->mapB};
+    for (void *p : ptrs) if (p) hipFree(p);
+    for (auto &e : h->ev) hipEventDestroy(e);
+    hipStreamDestroy(h->st);
+    delete h;
+}
+
+extern "C" void *slsqp_stream(slsqp_handle *h) { return (void *)h->st; }
+extern "C" int slsqp_sync(slsqp_handle *h) { hipSetDevice(h->dev); HIPCHK(hipStreamSynchronize(h->st)); return 0; }
+
+static int put(slsqp_handle *h, void *dst, const void *src, size_t bytes, int loc) {
+    if (!src) return 0;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, loc == SLSQP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->st));
+    if (loc == SLSQP_HOST) HIPCHK(hipStreamSynchronize(h->st));  // caller's buffer may be reused on return
+    return 0;
+}
+
+static bool is_diag(const double *M, int n) {
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) if (i != j && M[i * n + j] != 0.0) return false;
+    return true;
+}
+
+extern "C" int slsqp_set_costs(slsqp_handle *h, const double *Q, const double *R, const double *Qf, const double *Q_reg, const double *R_reg,
+                               const double *Q_reg_f) {
+    hipSetDevice(h->dev);
+    const int nx = h->d.nx, nu = h->d.nu;
+    if (!is_diag(Q, nx) || !is_diag(R, nu) || !is_diag(Qf, nx) || !is_diag(Q_reg, nx) || !is_diag(R_reg, nu) || !is_diag(Q_reg_f, nx))
+        return fail("Q,R,Qf,Q_reg,R_reg,Q_reg_f must be diagonal (HIP path); dense weights are not supported");
+    std::vector<double> v;
+    auto push = [&](const double *M, int n) { for (int i = 0; i < n; i++) v.push_back(M[i * n + i]); };
+    push(Q, nx); push(R, nu); push(Qf, nx); push(Q_reg, nx); push(R_reg, nu); push(Q_reg_f, nx);
+    for (int i = 0; i < nx + nu + nx; i++) if (!(v[i] > 0.0)) return fail("Q,R,Qf must be positive definite");
+    HIPCHK(hipMemcpy(h->cst, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->have_costs = true;
+    return 0;
+}
+
+extern "C" int slsqp_set_constraints(slsqp_handle *h, const double *G, const double *Gf, const double *gf) {
+    hipSetDevice(h->dev);
+    const int nx = h->d.nx, nz = h->nz;
+    for (int i = 0; i < 2 * nz; i++) for (int j = 0; j < nz; j++) {
+        const double want = (i % nz == j) ? (i < nz ? 1.0 : -1.0) : 0.0;
+        if (G[i * nz + j] != want) return fail("G must be [I;-I] (box constraints): general G is not supported by the HIP path");
+    }
+    for (int i = 0; i < 2 * nx; i++) for (int j = 0; j < nx; j++) {
+        const double want = (i % nx == j) ? (i < nx ? 1.0 : -1.0) : 0.0;
+        if (Gf[i * nx + j] != want) return fail("Gf must be [I;-I]");
+    }
+    HIPCHK(hipMemcpy(h->gf_raw, gf, sizeof(double) * 2 * nx, hipMemcpyHostToDevice));
+    h->have_cons = true;
+    return 0;
+}
+
+extern "C" int slsqp_update_dynamics(slsqp_handle *h, const double *A, const double *Bm, const double *E, const double *g, const double *g_N,
+                                     const double *c, int loc) {
+    hipSetDevice(h->dev);
+    const slsqp_dims &d = h->d;
+    const size_t B = h->B;
+    if (!A || !Bm || !g || !g_N || !c) return fail("A, B, g, g_N, c are required");
+    if (put(h, h->A, A, sizeof(double) * B * d.N * d.nx * d.nx, loc)) return -1;
+    if (put(h, h->Bm, Bm, sizeof(double) * B * d.N * d.nx * d.nu, loc)) return -1;
+    if (put(h, h->E, E, sizeof(double) * (d.N + 1) * d.nx * d.nw, loc)) return -1;
+    if (put(h, h->g, g, sizeof(double) * B * d.N * d.ni, loc)) return -1;
+    if (put(h, h->gN, g_N, sizeof(double) * B * d.ni_f, loc)) return -1;
+    if (put(h, h->c, c, sizeof(double) * B * d.N * d.nx, loc)) return -1;
+    BoundsArgs a{h->B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->ubg, h->lbg, 1e-10};
+    hipLaunchKernelGGL(k_set_bounds, dim3(1024), dim3(256), 0, h->st, a);
+    HIPCHK(hipGetLastError());
+    h->have_dyn = true;
+    return 0;
+}
+
+extern "C" int slsqp_update_linear_cost(slsqp_handle *h, const double *q, int loc) {
+    hipSetDevice(h->dev);
+    return put(h, h->q, q, sizeof(double) * (size_t)h->B * h->n, loc);
+}
+
+// ---- small mask kernels ------------------------------------------------------------------------------------
+__global__ void k_fill_int(int *p, int v, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+__global__ void k_negate(const double *x, double *y, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) y[i] = -x[i]; }
+// after a QP: instances whose QP failed drop out (forward_solve -> False, fast_SLS_jit.py:461-464)
+__global__ void k_post_qp(int B, const int *status, int *alive, int *infeas) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && alive[b]) { const int ok = (status[b] == 0 || status[b] == 4); if (!ok) { alive[b] = 0; infeas[b] = 1; } }
+}
+// after the convergence test: mask = instances that go on to Riccati + tightening (_step :318-326)
+__global__ void k_post_conv(int B, int rti, const int *conv, int *alive, int *mask, int *success, int *itnum, int *counter) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int m = 0;
+    if (alive[b]) {
+        if (conv[b]) { success[b] = 1; if (!rti) alive[b] = 0; }
+        else m = 1;
+    }
+    mask[b] = m;
+    if (m) { itnum[b] += 1; atomicAdd(counter, 1); }
+}
+__global__ void k_finish(int B, int rti, const int *alive, const int *infeas, int *success) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (rti) success[b] = (!infeas[b]) || success[b];           // fast_SLS_jit.py:295
+    else if (alive[b] || infeas[b]) success[b] = 0;             // hit MAX_ITER or infeasible (:304, :312)
+}
+__global__ void k_split_lu(int B, int mb, int nx, const double *l, const double *u, double *lbg, double *ubg, double *x0val) {
+    const int m = mb + nx;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < (size_t)B * m; idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = idx / m, r = idx % m;
+        if (r < mb) { lbg[(size_t)b * mb + r] = l[idx]; ubg[(size_t)b * mb + r] = u[idx]; }
+        else x0val[(size_t)b * nx + (r - mb)] = 0.5 * (l[idx] + u[idx]);
+    }
+}
+__global__ void k_gather_csc(int B, int cnt, int nnz, const int *map, const double *Ax, double *dst) {
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < (size_t)B * cnt; idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = idx / cnt, o = idx % cnt;
+        dst[idx] = Ax[(size_t)b * nnz + map[o]];
+    }
+}
+__global__ void k_join_y(int B, int mb, int nx, const double *dual, const double *pin, double *y) {
+    const int m = mb + nx;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < (size_t)B * m; idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = idx / m, r = idx % m;
+        y[idx] = r < mb ? dual[(size_t)b * mb + r] : pin[(size_t)b * nx + (r - mb)];
+    }
+}
+
+// ---- kernel dispatch ---------------------------------------------------------------------------------------
+template <int NX, int NU, int TV>
+static int launch_qp_tv(slsqp_handle *h, const QpArgs &a) {
+    const size_t lds = sizeof(double) * qp_lds_doubles<NX, NU>(h->d.N);
+    HIPCHK(hipFuncSetAttribute((const void *)k_qp<NX, NU, TV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_qp<NX, NU, TV>), dim3(h->B), dim3(64), lds, h->st, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// register tiling TV = ceil(n/64) rounded up to an instantiated value
+template <int NX, int NU, int T0, int T1, int T2>
+static int launch_qp_t(slsqp_handle *h, const QpArgs &a) {
+    const int tv = (h->n + 63) / 64;
+    if (tv <= T0) return launch_qp_tv<NX, NU, T0>(h, a);
+    if (tv <= T1) return launch_qp_tv<NX, NU, T1>(h, a);
+    if (tv <= T2) return launch_qp_tv<NX, NU, T2>(h, a);
+    return fail("horizon too long for the instantiated register tiling");
+}
+
+static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o) {
+    QpArgs a;
+    a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;
+    a.cst = costs_of(h); a.Linv = h->Linv; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
+    a.status = h->status; a.iters = h->iters; a.max_iter = o->qp_max_iter; a.eps = o->qp_eps;
+    if (h->d.nx == 4) return launch_qp_t<4, 1, 1, 2, 3>(h, a);
+    if (h->d.nx == 13) return launch_qp_t<13, 4, 3, 6, 9>(h, a);
+    return launch_qp_t<17, 4, 4, 7, 11>(h, a);
+}
+
+template <int NX, int NU>
+static int launch_sweep_t(slsqp_handle *h, const SweepArgs &a) {
+    const size_t lds = sizeof(double) * sweep_lds_doubles<NX, NU>();
+    hipLaunchKernelGGL((k_sweep<NX, NU>), dim3(h->B * (h->d.N + 1)), dim3(64), lds, h->st, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, const double *eta_f, double eps) {
+    SweepArgs a;
+    a.B = h->B; a.N = h->d.N; a.NW = h->d.nw; a.A = h->A; a.Bm = h->Bm; a.E = h->E; a.E_per_instance = 0; a.eta = eta; a.eta_f = eta_f;
+    a.run = run; a.cst = costs_of(h); a.K = h->K; a.beta = h->beta; a.beta_f = h->beta_f; a.eps = eps;
+    if (h->d.nx == 4) return launch_sweep_t<4, 1>(h, a);
+    if (h->d.nx == 13) return launch_sweep_t<13, 4>(h, a);
+    return launch_sweep_t<17, 4>(h, a);
+}
+
+static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
+
+extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts) {
+    hipSetDevice(h->dev);
+    if (!h->have_costs || !h->have_cons || !h->have_dyn) return fail("set_costs, set_constraints and update_dynamics must be called first");
+    slsqp_opts o;
+    if (opts) o = *opts; else slsqp_default_opts(&o);
+    const slsqp_dims &d = h->d;
+    const int B = h->B, gb = (B + 255) / 256;
+    // x_0 is pinned to -x0 (qp_jit.py:376-379)
+    if (loc == SLSQP_HOST) {
+        std::vector<double> neg((size_t)B * d.nx);
+        for (size_t i = 0; i < neg.size(); i++) neg[i] = -x0[i];
+        HIPCHK(hipMemcpy(h->x0val, neg.data(), neg.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        hipLaunchKernelGGL(k_negate, dim3((B * d.nx + 255) / 256), dim3(256), 0, h->st, x0, h->x0val, B * d.nx);
+    }
+    const bool rti = o.rti_steps > 0;
+    const int steps = rti ? o.rti_steps : o.max_sls_iter;
+    std::vector<float> tq, ts;
+    HIPCHK(hipEventRecord(h->ev[0], h->st));
+    hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->alive, 1, B);
+    hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->infeas, 0, B);
+    hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->success, 0, B);
+    {   // initialize_backoff at the top of every solve (fast_SLS_jit.py:281,299)
+        InitBackoffArgs ia{B, d.N, d.nx, d.nu, o.eps_backoff, nullptr, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u};
+        hipLaunchKernelGGL(k_init_backoff, dim3(B), dim3(256), 0, h->st, ia);
+    }
+    double acc_qp = 0, acc_sw = 0;
+    for (int i = 0; i < steps; i++) {
+        HIPCHK(hipEventRecord(h->ev[1], h->st));
+        if (launch_qp(h, h->alive, &o)) return -1;
+        HIPCHK(hipEventRecord(h->ev[2], h->st));
+        hipLaunchKernelGGL(k_post_qp, dim3(gb), dim3(256), 0, h->st, B, h->status, h->alive, h->infeas);
+        EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff};
+        hipLaunchKernelGGL(k_eta, dim3(B), dim3(256), 0, h->st, ea);
+        ConvArgs ca{B, h->n, h->primal, h->prev_primal, h->has_prev, h->alive, h->conv, o.conv_tol};
+        hipLaunchKernelGGL(k_conv, dim3(B), dim3(64), 0, h->st, ca);
+        HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), h->st));
+        hipLaunchKernelGGL(k_post_conv, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->conv, h->alive, h->mask, h->success, h->itnum, h->counter);
+        HIPCHK(hipEventRecord(h->ev[3], h->st));
+        if (launch_sweep(h, h->mask, h->eta, h->eta_f, o.eps_backoff)) return -1;
+        HIPCHK(hipEventRecord(h->ev[4], h->st));
+        TightenArgs ta{B, d.N, d.nx, d.nu, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1};
+        hipLaunchKernelGGL(k_tighten, dim3(B), dim3(128), 0, h->st, ta);
+        int nmask = 0;
+        HIPCHK(hipMemcpyAsync(&nmask, h->counter, sizeof(int), hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+        acc_qp += ev_ms(h->ev[1], h->ev[2]); acc_sw += ev_ms(h->ev[3], h->ev[4]);
+        if (!rti && nmask == 0) break;   // every instance converged or failed
+    }
+    // final QP: RTI always (fast_SLS_jit.py:293); converge mode only for instances that hit MAX_ITER (:311)
+    HIPCHK(hipEventRecord(h->ev[1], h->st));
+    if (launch_qp(h, h->alive, &o)) return -1;
+    HIPCHK(hipEventRecord(h->ev[2], h->st));
+    hipLaunchKernelGGL(k_finish, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->alive, h->infeas, h->success);
+    HIPCHK(hipEventRecord(h->ev[5], h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    acc_qp += ev_ms(h->ev[1], h->ev[2]);
+    h->t_total = ev_ms(h->ev[0], h->ev[5]); h->t_qp = acc_qp; h->t_sweep = acc_sw;
+    return 0;
+}
+
+extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms4) {
+    ms4[0] = h->t_total; ms4[1] = h->t_qp; ms4[2] = h->t_sweep; ms4[3] = h->t_total - h->t_qp - h->t_sweep;
+    return 0;
+}
+
+extern "C" int slsqp_get(slsqp_handle *h, const char *name, void *out, int loc) {
+    hipSetDevice(h->dev);
+    auto it = h->named.find(name);
+    if (it == h->named.end()) return fail(std::string("unknown result name: ") + name);
+    const size_t bytes = it->second.second * (size_t)h->B;
+    HIPCHK(hipMemcpyAsync(out, it->second.first, bytes, loc == SLSQP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+extern "C" int slsqp_reset(slsqp_handle *h) {
+    hipSetDevice(h->dev);
+    // reset_solver_to_zeros (fast_SLS_jit.py:424-442): eta/eta_f/iteration_number to zero, bounds and linear cost dropped.
+    // `_prev_primal_vec` is NOT cleared by the reference (quirk q5) and is not cleared here.
+    const slsqp_dims &d = h->d;
+    const size_t B = h->B;
+    HIPCHK(hipMemsetAsync(h->eta, 0, sizeof(double) * B * d.N * d.N * d.ni, h->st));
+    HIPCHK(hipMemsetAsync(h->eta_f, 0, sizeof(double) * B * (d.N + 1) * d.ni_f, h->st));
+    HIPCHK(hipMemsetAsync(h->itnum, 0, sizeof(int) * B, h->st));
+    HIPCHK(hipMemsetAsync(h->q, 0, sizeof(double) * B * h->n, h->st));
+    HIPCHK(hipMemsetAsync(h->K, 0, sizeof(double) * B * d.N * (d.N + 1) * d.nu * d.nx, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    h->have_dyn = false;
+    return 0;
+}
+
+// ---- QP-level boundary (osqp_generated look-alike, batched) -------------------------------------------------
+extern "C" int slsqp_qp_update_data_mat(slsqp_handle *h, const double *P_x, const double *A_x, int loc) {
+    hipSetDevice(h->dev);
+    const slsqp_dims &d = h->d;
+    int n, m, nnzP, nnzA;
+    slsqp_qp_nnz(&d, &n, &m, &nnzP, &nnzA);
+    if (P_x) {   // diagonal of 2*blkdiag(Q,R,...,Qf): take instance 0 (weights are batch-constant)
+        std::vector<double> p0(n);
+        HIPCHK(hipMemcpy(p0.data(), P_x, sizeof(double) * n, loc == SLSQP_HOST ? hipMemcpyHostToHost : hipMemcpyDeviceToHost));
+        std::vector<double> cur(2 * d.nx + d.nu);
+        for (int i = 0; i < d.nx; i++) cur[i] = 0.5 * p0[i];
+        for (int i = 0; i < d.nu; i++) cur[d.nx + i] = 0.5 * p0[d.nx + i];
+        for (int i = 0; i < d.nx; i++) cur[d.nx + d.nu + i] = 0.5 * p0[(size_t)h->nz * d.N + i];
+        HIPCHK(hipMemcpy(h->cst, cur.data(), sizeof(double) * cur.size(), hipMemcpyHostToDevice));
+        h->have_costs = true;
+    }
+    if (A_x) {
+        const double *src = A_x;
+        double *tmp = nullptr;
+        if (loc == SLSQP_HOST) {
+            HIPCHK(hipMalloc((void **)&tmp, sizeof(double) * (size_t)h->B * nnzA));
+            HIPCHK(hipMemcpy(tmp, A_x, sizeof(double) * (size_t)h->B * nnzA, hipMemcpyHostToDevice));
+            src = tmp;
+        }
+        hipLaunchKernelGGL(k_gather_csc, dim3(1024), dim3(256), 0, h->st, h->B, d.N * d.nx * d.nx, nnzA, h->mapA, src, h->A);
+        hipLaunchKernelGGL(k_gather_csc, dim3(1024), dim3(256), 0, h->st, h->B, d.N * d.nx * d.nu, nnzA, h->mapB, src, h->Bm);
+        HIPCHK(hipStreamSynchronize(h->st));
+        if (tmp) hipFree(tmp);
+    }
+    return 0;
+}
+
+extern "C" int slsqp_qp_update_data_vec(slsqp_handle *h, const double *q, const double *l, const double *u, int loc) {
+    hipSetDevice(h->dev);
+    const size_t B = h->B;
+    if (q && put(h, h->q, q, sizeof(double) * B * h->n, loc)) return -1;
+    if (l && u) {
+        const double *dl = l, *du = u;
+        double *tmp = nullptr;
+        if (loc == SLSQP_HOST) {
+            HIPCHK(hipMalloc((void **)&tmp, sizeof(double) * 2 * B * h->m));
+            HIPCHK(hipMemcpy(tmp, l, sizeof(double) * B * h->m, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(tmp + B * h->m, u, sizeof(double) * B * h->m, hipMemcpyHostToDevice));
+            dl = tmp; du = tmp + B * h->m;
+        }
+        hipLaunchKernelGGL(k_split_lu, dim3(1024), dim3(256), 0, h->st, h->B, h->mb, h->d.nx, dl, du, h->lbg, h->ubg, h->x0val);
+        HIPCHK(hipStreamSynchronize(h->st));
+        if (tmp) hipFree(tmp);
+    }
+    h->have_dyn = true;
+    return 0;
+}
+
+extern "C" int slsqp_qp_solve(slsqp_handle *h, double *x, double *y, int *status, int *iters, int loc, const slsqp_opts *opts) {
+    hipSetDevice(h->dev);
+    if (!h->have_costs) return fail("costs not set");
+    slsqp_opts o;
+    if (opts) o = *opts; else slsqp_default_opts(&o);
+    HIPCHK(hipEventRecord(h->ev[0], h->st));
+    if (launch_qp(h, nullptr, &o)) return -1;
+    HIPCHK(hipEventRecord(h->ev[1], h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    h->t_total = h->t_qp = ev_ms(h->ev[0], h->ev[1]); h->t_sweep = 0;
+    const hipMemcpyKind kd = loc == SLSQP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (x) HIPCHK(hipMemcpy(x, h->primal, sizeof(double) * (size_t)h->B * h->n, kd));
+    if (y) {
+        double *tmp = nullptr;
+        HIPCHK(hipMalloc((void **)&tmp, sizeof(double) * (size_t)h->B * h->m));
+        hipLaunchKernelGGL(k_join_y, dim3(1024), dim3(256), 0, h->st, h->B, h->mb, h->d.nx, h->dual, h->pin_dual, tmp);
+        HIPCHK(hipStreamSynchronize(h->st));
+        HIPCHK(hipMemcpy(y, tmp, sizeof(double) * (size_t)h->B * h->m, kd));
+        hipFree(tmp);
+    }
+    if (status) HIPCHK(hipMemcpy(status, h->status, sizeof(int) * h->B, kd));
+    if (iters) HIPCHK(hipMemcpy(iters, h->iters, sizeof(int) * h->B, kd));
+    return 0;
+}
+
+// ---- sweep-level boundary -----------------------------------------------------------------------------------
+extern "C" int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta_f, double *K, double *beta, double *beta_f, double *backoff,
+                           double *backoff_f, int loc) {
+    hipSetDevice(h->dev);
+    if (!h->have_costs) return fail("costs not set");
+    const slsqp_dims &d = h->d;
+    const size_t B = h->B;
+    if (put(h, h->eta, eta, sizeof(double) * B * d.N * d.N * d.ni, loc)) return -1;
+    if (put(h, h->eta_f, eta_f, sizeof(double) * B * (d.N + 1) * d.ni_f, loc)) return -1;
+    HIPCHK(hipEventRecord(h->ev[0], h->st));
+    if (launch_sweep(h, nullptr, h->eta, h->eta_f, 1e-10)) return -1;
+    HIPCHK(hipEventRecord(h->ev[1], h->st));
+    TightenArgs ta{h->B, d.N, d.nx, d.nu, h->beta, h->beta_f, h->g, h->gf_raw, h->c, nullptr, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 0};
+    hipLaunchKernelGGL(k_tighten, dim3(h->B), dim3(128), 0, h->st, ta);
+    HIPCHK(hipEventRecord(h->ev[2], h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    h->t_sweep = ev_ms(h->ev[0], h->ev[1]); h->t_total = ev_ms(h->ev[0], h->ev[2]); h->t_qp = 0;
+    const hipMemcpyKind kd = loc == SLSQP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (K) HIPCHK(hipMemcpy(K, h->K, sizeof(double) * B * d.N * (d.N + 1) * d.nu * d.nx, kd));
+    if (beta) HIPCHK(hipMemcpy(beta, h->beta, sizeof(double) * B * d.N * d.N * d.ni, kd));
+    if (beta_f) HIPCHK(hipMemcpy(beta_f, h->beta_f, sizeof(double) * B * (d.N + 1) * d.ni_f, kd));
+    if (backoff) HIPCHK(hipMemcpy(backoff, h->backoff, sizeof(double) * B * d.N * d.ni, kd));
+    if (backoff_f) HIPCHK(hipMemcpy(backoff_f, h->backoff_f, sizeof(double) * B * d.ni_f, kd));
+    return 0;
+}

@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference's fast-SLS interface, batched, on top of the C-ABI (include/slsqp.h).
+
+`BatchedFastSLS` keeps the method names, argument meaning and result keys of the reference's
+`fast_SLS` (solver/fast_SLS_jit.py:195-646) with a leading batch axis B on every array:
+
+    reference (single instance)                      here (B instances, one GPU)
+    fast_SLS(N,Q,R,m_LTV,Qf,Q_reg,R_reg,Q_reg_f)     BatchedFastSLS(N,Q,R,model,Qf,Q_reg,R_reg,Q_reg_f,batch=B)
+    .update_dynamics_list(A,B,E,g,c)                 .update_dynamics_list(A[B,N,nx,nx],B[B,N,nx,nu],E[N+1,nx,nw],
+                                                                           g[B,N,ni],g_N[B,ni_f],c[B,N,nx])
+    .update_linear_cost(q)                           .update_linear_cost(q[B,n])
+    .set_rti_steps(k)                                .set_rti_steps(k)
+    .solve(x0) -> dict                               .solve(x0[B,nx]) -> dict of [B,...] arrays (same keys)
+    .reset_solver_to_zeros()                         .reset_solver_to_zeros()
+
+`fast_SLS` (lower case, the reference's class name) is the B=1 view returning the reference's exact shapes,
+so SCP_SLS-style callers can switch by changing one import.  All arithmetic runs in the HIP library; this
+module only moves arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class BatchedFastSLS:
+    def __init__(self, N, Q, R, model, Qf, Q_reg=None, R_reg=None, Q_reg_f=None, batch=1, device=0):
+        self.lib = L.load()
+        self.N, self.m, self.B = int(N), model, int(batch)
+        nx, nu = model.nx, model.nu
+        self.Q, self.R, self.Qf = _c(Q), _c(R), _c(Qf)
+        # OCP defaults (solver/ocp.py:14-27)
+        self.Q_reg = _c(np.eye(nx) if Q_reg is None else Q_reg)
+        self.R_reg = _c(np.eye(nu) if R_reg is None else R_reg)
+        self.Q_reg_f = _c(np.eye(nx) if Q_reg_f is None else Q_reg_f)
+        self.dims = L.Dims(nx, nu, model.nw, self.N, model.ni, model.ni_f)
+        self.n = model.nz * self.N + nx
+        self.mb = self.N * (nx + model.ni) + model.ni_f
+        self.h = self.lib.slsqp_create(C.byref(self.dims), self.B, device)
+        if not self.h:
+            raise RuntimeError("slsqp_create: " + self.lib.slsqp_last_error().decode())
+        self.opts = L.Opts()
+        self.lib.slsqp_default_opts(C.byref(self.opts))
+        self.opts.rti_steps = 0       # fast_SLS default: iterate to convergence (fast_SLS_jit.py:214)
+        self.verbose = False
+        self.save_it_data = False
+        self.CONV_EPS = 1e-6
+        self._push_costs()
+        G, Gf, gf = _c(model.G), _c(model.Gf), _c(model.gf)
+        L.check(self.lib.slsqp_set_constraints(self.h, _ptr(G), _ptr(Gf), _ptr(gf)))
+        self._E = _c(np.stack([model.E] * (self.N + 1)))
+
+    def _push_costs(self):
+        L.check(self.lib.slsqp_set_costs(self.h, _ptr(self.Q), _ptr(self.R), _ptr(self.Qf), _ptr(self.Q_reg), _ptr(self.R_reg), _ptr(self.Q_reg_f)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.slsqp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference surface -------------------------------------------------------------------------
+    def set_rti_steps(self, steps):
+        self.opts.rti_steps = 0 if (steps is None or steps <= 0) else int(steps)
+
+    def set_regularisers(self, Q_reg, R_reg, Q_reg_f):
+        """SCP_SLS pokes .Q_reg/.R_reg/.Q_reg_f after construction (SCP_SLS_jit.py:386-388)."""
+        self.Q_reg, self.R_reg, self.Q_reg_f = _c(Q_reg), _c(R_reg), _c(Q_reg_f)
+        self._push_costs()
+
+    def update_dynamics_list(self, A, Bm, E=None, g=None, g_N=None, c=None):
+        B, N, m = self.B, self.N, self.m
+        A, Bm, g, g_N, c = _c(A), _c(Bm), _c(g), _c(g_N), _c(c)
+        assert A.shape == (B, N, m.nx, m.nx) and Bm.shape == (B, N, m.nx, m.nu), (A.shape, Bm.shape)
+        assert g.shape == (B, N, m.ni) and g_N.shape == (B, m.ni_f) and c.shape == (B, N, m.nx)
+        if E is not None:
+            self._E = _c(E)
+            assert self._E.shape == (N + 1, m.nx, m.nw)
+        L.check(self.lib.slsqp_update_dynamics(self.h, _ptr(A), _ptr(Bm), _ptr(self._E), _ptr(g), _ptr(g_N), _ptr(c), L.HOST))
+
+    def update_linear_cost(self, q):
+        q = _c(q)
+        assert q.shape == (self.B, self.n)
+        L.check(self.lib.slsqp_update_linear_cost(self.h, _ptr(q), L.HOST))
+
+    def reset_solver_to_zeros(self):
+        L.check(self.lib.slsqp_reset(self.h))
+
+    def get(self, name, shape, dtype=np.float64):
+        out = np.empty((self.B,) + tuple(shape), dtype=dtype)
+        L.check(self.lib.slsqp_get(self.h, name.encode(), out.ctypes.data_as(C.c_void_p), L.HOST))
+        return out
+
+    def timing_ms(self):
+        t = np.zeros(4)
+        self.lib.slsqp_last_timing(self.h, _ptr(t))
+        return dict(total=t[0], qp=t[1], sweep=t[2], other=t[3])
+
+    def solve(self, x0, fetch=True):
+        """x0: (B,nx) = x_nom0 - x_meas (the argument SCP_SLS.socp_step passes, SCP_SLS_jit.py:408-410)."""
+        x0 = _c(x0)
+        assert x0.shape == (self.B, self.m.nx)
+        L.check(self.lib.slsqp_solve(self.h, _ptr(x0), L.HOST, C.byref(self.opts)))
+        return self.post_processing_solution() if fetch else None
+
+    def post_processing_solution(self):
+        """Keys of fast_SLS.post_processing_solution (fast_SLS_jit.py:615-643), batch axis first."""
+        m, N, B = self.m, self.N, self.B
+        nx, nu, ni, nif, nz = m.nx, m.nu, m.ni, m.ni_f, m.nz
+        pv = self.get("primal_vec", (self.n,))
+        dv = self.get("dual_vec", (self.mb,))
+        st = pv[:, : nz * N].reshape(B, N, nz)
+        primal_x = np.concatenate([st[:, :, :nx], pv[:, None, nz * N:]], axis=1).transpose(0, 2, 1).copy()  # (B,nx,N+1)
+        primal_u = st[:, :, nx:].transpose(0, 2, 1).copy()                                                  # (B,nu,N)
+        dual_mu_f = dv[:, -nif:].copy()
+        dual_mu = dv[:, :-nif].reshape(B, N, nx + ni)[:, :, nx:].transpose(0, 2, 1).copy()                   # (B,ni,N)
+        K = self.get("K", (N, N + 1, nu, nx))
+        out = dict(
+            iteration_number=self.get("iteration_number", (), np.int32),
+            success=self.get("success", (), np.int32).astype(bool),
+            status=self.get("status", (), np.int32),
+            qp_iters=self.get("qp_iters", (), np.int32),
+            cost_nominal=self.get("cost_nominal", ()),
+            cost_tube=np.full(B, np.nan), cost=np.full(B, np.nan),
+            primal_x=primal_x, primal_u=primal_u, primal_vec=pv, dual_vec=dv, dual_mu=dual_mu, dual_mu_f=dual_mu_f,
+            eta=self.get("eta", (N, N, ni)), eta_f=self.get("eta_f", (N + 1, nif)),
+            K=K, K_mat=K.transpose(0, 1, 3, 2, 4).reshape(B, N * nu, (N + 1) * nx),
+            Phi_x=None, Phi_u=None, Phi_x_mat=None, Phi_u_mat=None,
+            beta=self.get("beta", (N, N, ni)), beta_f=self.get("beta_f", (N + 1, nif)),
+            backoff=self.get("backoff", (N, ni)), backoff_f=self.get("backoff_f", (nif,)),
+            backoff_x=self.get("backoff_x", (N + 1, nx)), backoff_u=self.get("backoff_u", (N, nu)),
+            kkt=self.get("kkt", (4,)),
+        )
+        t = self.timing_ms()
+        out["t_qp_ms"] = t["qp"]
+        out["t_backward_ms"] = t["sweep"]
+        return out
+
+    # ---- QP-level / sweep-level boundaries (tests, drop-in for the generated-OSQP module) -------------
+    def qp_nnz(self):
+        n, m, nP, nA = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.lib.slsqp_qp_nnz(C.byref(self.dims), C.byref(n), C.byref(m), C.byref(nP), C.byref(nA))
+        return n.value, m.value, nP.value, nA.value
+
+    def qp_update_data_mat(self, P_x=None, A_x=None):
+        P_x = None if P_x is None else _c(P_x)
+        A_x = None if A_x is None else _c(A_x)
+        L.check(self.lib.slsqp_qp_update_data_mat(self.h, _ptr(P_x), _ptr(A_x), L.HOST))
+        return 0
+
+    def qp_update_data_vec(self, q=None, l=None, u=None):
+        q, l, u = (None if v is None else _c(v) for v in (q, l, u))
+        L.check(self.lib.slsqp_qp_update_data_vec(self.h, _ptr(q), _ptr(l), _ptr(u), L.HOST))
+        return 0
+
+    def qp_solve(self):
+        n, m = self.n, self.mb + self.m.nx
+        x = np.empty((self.B, n))
+        y = np.empty((self.B, m))
+        st = np.empty(self.B, dtype=np.int32)
+        it = np.empty(self.B, dtype=np.int32)
+        L.check(self.lib.slsqp_qp_solve(self.h, _ptr(x), _ptr(y), st.ctypes.data_as(C.c_void_p), it.ctypes.data_as(C.c_void_p), L.HOST, C.byref(self.opts)))
+        return x, y, st, it, self.timing_ms()["qp"] * 1e-3
+
+    def sweep(self, eta, eta_f):
+        m, N, B = self.m, self.N, self.B
+        eta, eta_f = _c(eta), _c(eta_f)
+        K = np.empty((B, N, N + 1, m.nu, m.nx))
+        beta = np.empty((B, N, N, m.ni))
+        beta_f = np.empty((B, N + 1, m.ni_f))
+        bo = np.empty((B, N, m.ni))
+        bof = np.empty((B, m.ni_f))
+        L.check(self.lib.slsqp_sweep(self.h, _ptr(eta), _ptr(eta_f), _ptr(K), _ptr(beta), _ptr(beta_f), _ptr(bo), _ptr(bof), L.HOST))
+        return dict(K=K, beta=beta, beta_f=beta_f, backoff=bo, backoff_f=bof)
+
+
+class fast_SLS(BatchedFastSLS):
+    """B = 1 view with the reference's exact argument and result shapes (fast_SLS_jit.py:195)."""
+
+    def __init__(self, N, Q, R, m, Qf, Q_reg=None, R_reg=None, Q_reg_f=None, device=0):
+        super().__init__(N, Q, R, m, Qf, Q_reg, R_reg, Q_reg_f, batch=1, device=device)
+
+    def update_dynamics_list(self, new_list_A, new_list_B, new_list_E=None, new_list_g=None, c_offset_list=None):
+        A = np.stack([np.asarray(a, dtype=float) for a in new_list_A])[None]
+        Bm = np.stack([np.asarray(b, dtype=float) for b in new_list_B])[None]
+        E = None if new_list_E is None else np.stack([np.asarray(e, dtype=float) for e in new_list_E])
+        g = np.stack([np.asarray(x, dtype=float).ravel() for x in new_list_g[:-1]])[None]
+        gN = np.asarray(new_list_g[-1], dtype=float).ravel()[None]
+        c = np.stack([np.asarray(x, dtype=float).ravel() for x in c_offset_list])[None]
+        super().update_dynamics_list(A, Bm, E, g, gN, c)
+
+    def update_linear_cost(self, q_cost_lin):
+        super().update_linear_cost(np.asarray(q_cost_lin, dtype=float).reshape(1, -1))
+
+    def solve(self, x0):
+        out = super().solve(np.asarray(x0, dtype=float).reshape(1, -1))
+        return {k: (v[0] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == 1 else v) for k, v in out.items()}

@@ -1,0 +1,110 @@
+"""Seeded fast-SLS problem instances built from the golden fixtures (test helper, CPU only).
+
+An instance is what SCP_SLS.update_jacobian (solver/SCP_SLS_jit.py:251-366) hands to
+fast_SLS.update_dynamics_list / update_linear_cost / solve:
+  A_k, B_k   Jacobians of RK4 ddyn along a nominal (finite differences of the reference's own ddyn, stored in
+             tests/golden/sweep_*.npz by gen_golden.py)
+  c_k        f(z_k, v_k) - z_{k+1}
+  g_k        g - G [z_k; v_k],  g_N = gf - Gf z_N
+  q          2 H y_nom
+  x0_arg     x_nom0 - x_meas
+"""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+from robust_nonlinear_mpc_amd import get_model
+
+FIXTURE = {"pendulum": "sweep_pendulum_N10_s0.npz", "quadrotor": "sweep_quadrotor_N20_s0.npz", "rocket": "sweep_rocket_N20_s0.npz"}
+
+
+class Instance:
+    pass
+
+
+def make_instance(model_name, seed=0, x0_amp=0.2, c_amp=1e-3):
+    m = get_model(model_name)
+    g = dict(np.load(os.path.join(GOLDEN, FIXTURE[model_name])))
+    N = int(g["N"])
+    nx, nu, nz = m.nx, m.nu, m.nz
+    rng = np.random.default_rng(1000 + seed)
+    inst = Instance()
+    inst.m, inst.N = m, N
+    inst.A, inst.B = g["A"].copy(), g["B"].copy()
+    # perturb the Jacobians a little per seed so that instances differ (batch axis)
+    inst.A += 1e-3 * rng.normal(size=inst.A.shape)
+    inst.B += 1e-3 * rng.normal(size=inst.B.shape)
+    X, U = g["X"].copy(), g["U"].copy()  # nominal (N+1,nx), (N,nu)
+    inst.X, inst.U = X, U
+    inst.c = c_amp * rng.normal(size=(N, nx))
+    G, Gf = m.G, m.Gf
+    inst.g_list = [m.g - G @ np.concatenate([X[k], U[k]]) for k in range(N)] + [m.gf - Gf @ X[N]]
+    # cost is centred on the neutral state: deviation coordinates
+    Hd = np.concatenate([np.concatenate([np.diag(m.Q), np.diag(m.R)])] * N + [np.diag(m.Qf)])
+    y_nom = np.concatenate([np.concatenate([X[k] - m.x_ref, U[k] - m.u_ref]) for k in range(N)] + [X[N] - m.x_ref])
+    inst.q = 2.0 * Hd * y_nom
+    scale = 0.5 * (m.x_ub - m.x_lb)
+    inst.x0_arg = x0_amp * 0.1 * scale * rng.uniform(-1, 1, nx)
+    inst.E = np.stack([m.E] * (N + 1))
+    return inst
+
+
+def stack(insts, attr):
+    return np.stack([np.asarray(getattr(i, attr)) for i in insts])
+
+
+# ---- runners shared by tests, smoke() and bench.py --------------------------------------------------------
+def oracle_dims(inst):
+    from oracle import oracle as O
+    m = inst.m
+    return O.dims_of(m.nx, m.nu, m.nw, inst.N, m.ni, m.ni_f)
+
+
+def qp1_bounds(inst):
+    """l,u (reference row layout incl. x0 rows) of the un-tightened QP, via the oracle's bookkeeping restatement."""
+    from oracle import oracle as O
+    m = inst.m
+    qp = O.OracleQP(oracle_dims(inst), m.G, m.Gf, m.g, m.gf, m.Q, m.R, m.Qf)
+    qp.update_dynamics(inst.A, inst.B, inst.g_list)
+    qp.offset_constraints(inst.c.T)
+    return qp.bounds_with_x0(inst.x0_arg)
+
+
+def run_oracle_fastsls(inst, rti_steps=1, settings=None, prev_primal=None):
+    from oracle import oracle as O
+    m = inst.m
+    f = O.OracleFastSLS(oracle_dims(inst), m.G, m.Gf, m.g, m.gf, inst.E, m.Q, m.R, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f,
+                        settings or O.tight_settings())
+    f.set_rti_steps(rti_steps)
+    f.update_dynamics_list(inst.A, inst.B, inst.E, inst.g_list, inst.c)
+    f.update_linear_cost(inst.q)
+    if prev_primal is not None:
+        f._prev_primal = prev_primal.copy()
+    out = f.solve(inst.x0_arg)
+    out["_qp_info"] = f.qp.last_info
+    return out
+
+
+def make_gpu_solver(insts, device=0):
+    from robust_nonlinear_mpc_amd import BatchedFastSLS
+    m, N = insts[0].m, insts[0].N
+    return BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=len(insts), device=device)
+
+
+def push_instances(f, insts):
+    N = insts[0].N
+    g = np.stack([np.stack(i.g_list[:N]) for i in insts])
+    gN = np.stack([i.g_list[N] for i in insts])
+    f.update_dynamics_list(stack(insts, "A"), stack(insts, "B"), insts[0].E, g, gN, stack(insts, "c"))
+    f.update_linear_cost(stack(insts, "q"))
+
+
+def run_gpu_fastsls(insts, rti_steps=1, solver=None):
+    f = solver or make_gpu_solver(insts)
+    f.set_rti_steps(rti_steps)
+    push_instances(f, insts)
+    out = f.solve(stack(insts, "x0_arg"))
+    if solver is None:
+        f.close()
+    return out

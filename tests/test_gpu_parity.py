@@ -1,0 +1,150 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star: trajectories to 1e-6 rel):
+  sweep (K, beta, back-offs) vs the golden vectors of the reference's own kernels: 1e-9 rel
+  QP primal vs oracle (OSQP restatement driven to eps 1e-9 + polish): 1e-6 rel; KKT certificate <= 1e-8
+  full fast-SLS step (2 QPs + sweep): primal 1e-6 rel, back-offs 1e-6 rel
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from problems import (make_instance, make_gpu_solver, oracle_dims, push_instances, qp1_bounds, run_gpu_fastsls,
+                      run_oracle_fastsls, stack)
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b)))
+
+
+SWEEP_CASES = ["sweep_pendulum_N10_s0.npz", "sweep_pendulum_N3_s2.npz", "sweep_quadrotor_N20_s0.npz", "sweep_rocket_N20_s0.npz",
+               "sweep_rocket_N5_s1.npz"]
+
+
+@pytest.mark.parametrize("case", SWEEP_CASES)
+def test_sweep_vs_reference_golden(case):
+    from robust_nonlinear_mpc_amd import BatchedFastSLS, get_model
+    g = dict(np.load(os.path.join(GOLDEN, case)))
+    name = case.split("_")[1]
+    m = get_model(name)
+    N = int(g["N"])
+    B = 3
+    f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, g["Q_reg"], g["R_reg"], g["Q_reg_f"], batch=B)
+    rng = np.random.default_rng(5)
+    # instance 0 = the golden case; the others are perturbed copies (must not disturb instance 0)
+    A = np.stack([g["A"]] + [g["A"] + 1e-2 * rng.normal(size=g["A"].shape) for _ in range(B - 1)])
+    Bm = np.stack([g["B"]] * B)
+    zeros = lambda *s: np.zeros(s)
+    f.update_dynamics_list(A, Bm, g["E"], zeros(B, N, m.ni), zeros(B, m.ni_f), zeros(B, N, m.nx))
+    out = f.sweep(np.stack([g["eta"]] * B), np.stack([g["eta_f"]] * B))
+    f.close()
+    assert relerr(out["K"][0], g["K"]) < 1e-9
+    assert relerr(out["beta"][0], g["beta"]) < 1e-9
+    assert relerr(out["beta_f"][0], g["beta_f"]) < 1e-9
+    assert relerr(out["backoff"][0], g["backoff"]) < 1e-9
+    assert relerr(out["backoff_f"][0], g["backoff_f"]) < 1e-9
+    assert relerr(out["K"][1], g["K"]) > 1e-6  # perturbed instance really differs
+
+
+@pytest.mark.parametrize("model,amps", [("pendulum", (0.2, 1.0)), ("quadrotor", (0.2, 1.0, 2.0)), ("rocket", (0.2, 1.0))])
+def test_qp_vs_oracle(model, amps):
+    from oracle import oracle as O
+    insts = [make_instance(model, s, a) for a in amps for s in range(3)]
+    m = insts[0].m
+    f = make_gpu_solver(insts)
+    push_instances(f, insts)
+    lu = [qp1_bounds(i) for i in insts]
+    f.qp_update_data_vec(stack(insts, "q"), np.stack([x[0] for x in lu]), np.stack([x[1] for x in lu]))
+    x, y, st, it, _ = f.qp_solve()
+    f.close()
+    for b, inst in enumerate(insts):
+        d = oracle_dims(inst)
+        l, u = lu[b]
+        xo, yo, info = O.qp_solve(d, inst.A, inst.B, m.G, m.Gf, m.Q, m.R, m.Qf, inst.q, l, u, O.tight_settings())
+        assert st[b] == 0, f"instance {b}: status {st[b]} after {it[b]} its"
+        k = O.qp_kkt(d, inst.A, inst.B, m.G, m.Gf, m.Q, m.R, m.Qf, inst.q, l, u, x[b], y[b])
+        scale = max(1.0, np.abs(inst.q).max())
+        assert k["stationarity"] < 1e-8 * scale and k["primal"] < 1e-8 and k["dual_sign"] < 1e-8 and k["complementarity"] < 1e-7 * scale, k
+        if info.status == 1 and info.polish_status == 1:
+            assert relerr(x[b], xo) < 1e-6
+            act = np.abs(yo[: -m.nx]) > 1e-6
+            assert np.allclose(y[b][: -m.nx][act], yo[: -m.nx][act], rtol=1e-5, atol=1e-6 * scale)
+
+
+def test_qp_csc_boundary_matches_dense_boundary():
+    """update_data_mat(P_x, A_x) in the reference's CSC order (qp_jit.py:671-698) == update_dynamics with dense blocks."""
+    import scipy.sparse as sp
+    inst = make_instance("pendulum", 0, 1.0)
+    m, N = inst.m, inst.N
+    nx, nu, nz, ni = m.nx, m.nu, m.nz, m.ni
+    rows = []
+    n = m.n_var(N)
+    M = np.zeros((m.m_con(N), n))
+    r = 0
+    for k in range(N):
+        M[r:r + nx, k * nz:k * nz + nx] = inst.A[k]; M[r:r + nx, k * nz + nx:(k + 1) * nz] = inst.B[k]
+        M[r:r + nx, (k + 1) * nz:(k + 1) * nz + nx] = -np.eye(nx); r += nx
+        M[r:r + ni, k * nz:(k + 1) * nz] = m.G; r += ni
+    M[r:r + m.ni_f, N * nz:] = m.Gf; r += m.ni_f
+    M[r:r + nx, :nx] = np.eye(nx)
+    pattern = (M != 0)
+    for k in range(N):  # frozen dense pattern of A_k,B_k (qp_jit.py:90-99)
+        pattern[k * (nx + ni):k * (nx + ni) + nx, k * nz:(k + 1) * nz] = True
+    coo = sp.coo_matrix(pattern)
+    csc = sp.csc_matrix((M[coo.row, coo.col], (coo.row, coo.col)), shape=M.shape)
+    csc.sort_indices()
+    f = make_gpu_solver([inst])
+    nn, mm, nP, nA = f.qp_nnz()
+    assert (nn, mm, nA) == (54, 152, 352) and csc.nnz == nA  # n, m, nnz(A) of pendulum N=10
+    l, u = qp1_bounds(inst)
+    Hd = 2 * np.concatenate([np.concatenate([np.diag(m.Q), np.diag(m.R)])] * N + [np.diag(m.Qf)])
+    f.qp_update_data_mat(Hd[None], csc.data[None])
+    f.qp_update_data_vec(inst.q[None], l[None], u[None])
+    x1, y1, st1, _, _ = f.qp_solve()
+    push_instances(f, [inst])
+    f.qp_update_data_vec(inst.q[None], l[None], u[None])
+    x2, y2, st2, _, _ = f.qp_solve()
+    f.close()
+    assert st1[0] == 0 and st2[0] == 0
+    assert np.allclose(x1, x2, rtol=0, atol=1e-12) and np.allclose(y1, y2, rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("model,rti", [("pendulum", 1), ("pendulum", 2), ("quadrotor", 2), ("rocket", 1)])
+def test_fastsls_step_vs_oracle(model, rti):
+    insts = [make_instance(model, s, a) for a in (0.3, 1.0) for s in range(2)]
+    out = run_gpu_fastsls(insts, rti_steps=rti)
+    for b, inst in enumerate(insts):
+        ref = run_oracle_fastsls(inst, rti_steps=rti)
+        assert bool(out["success"][b]) == bool(ref["success"])
+        if not ref["success"]:
+            continue
+        assert out["iteration_number"][b] == ref["iteration_number"]
+        assert relerr(out["primal_vec"][b], ref["primal_vec"]) < 1e-6
+        assert relerr(out["backoff"][b], ref["backoff"]) < 1e-6
+        assert relerr(out["backoff_f"][b], ref["backoff_f"]) < 1e-6
+        assert relerr(out["backoff_x"][b], ref["backoff_x"]) < 1e-6
+        assert relerr(out["beta"][b], ref["beta"]) < 1e-6
+        assert np.allclose(out["primal_x"][b], ref["primal_x"], rtol=1e-6, atol=1e-7)
+        assert np.allclose(out["primal_u"][b], ref["primal_u"], rtol=1e-6, atol=1e-7)
+        assert abs(out["cost_nominal"][b] - ref["cost_nominal"]) < 1e-6 * max(1.0, abs(ref["cost_nominal"]))
+
+
+def test_convergence_state_leaks_across_calls_quirk_q5():
+    """Second RTI call with (almost) the same primal: _step returns True, Riccati + tightening are skipped and the
+    back-offs stay at their initial N*1e-5 values (fast_SLS_jit.py:318-320, 444-454)."""
+    insts = [make_instance("pendulum", s, 0.5) for s in range(2)]
+    f = make_gpu_solver(insts)
+    out1 = run_gpu_fastsls(insts, rti_steps=1, solver=f)
+    out2 = run_gpu_fastsls(insts, rti_steps=1, solver=f)
+    f.close()
+    N = insts[0].N
+    assert np.all(out1["iteration_number"] == 1)
+    assert np.all(out2["iteration_number"] == 1)          # not incremented: tightening skipped
+    assert np.allclose(out2["backoff"], N * 1e-5)
+    assert np.allclose(out2["backoff_x"], 0.0)
+    assert np.all(out2["success"])

@@ -92,7 +92,7 @@ int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *op
 /* Fetch a result array by name into `out` (host or device).  Names and shapes (B leading):
    primal_vec (n) dual_vec (m-nx) cost_nominal (1) status[int32] (1) qp_iters[int32] (1) iteration_number[int32] (1)
    beta (N,N,ni) beta_f (N+1,ni_f) backoff (N,ni) backoff_f (ni_f) backoff_x (N+1,nx) backoff_u (N,nu)
-   eta (N,N,ni) eta_f (N+1,ni_f) K (N,N+1,nu,nx) ubg (m-nx) lbg (m-nx) kkt (4) */
+   eta (N,N,ni) eta_f (N+1,ni_f) K (N,N+1,nu,nx) ubg (m-nx) lbg (m-nx) kkt (8) pin_dual (nx) success[int32] (1) */
 int slsqp_get(slsqp_handle *h, const char *name, void *out, int loc);
 int slsqp_reset(slsqp_handle *h);
 int slsqp_sync(slsqp_handle *h);

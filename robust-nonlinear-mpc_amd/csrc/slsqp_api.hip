@@ -98,7 +98,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->x0val, B * nx); rc |= dalloc(&h->gf_raw, (size_t)nif); rc |= dalloc(&h->cst, (size_t)(3 * nx + 2 * nu) * 2);
     rc |= dalloc(&h->ubg, B * h->mb); rc |= dalloc(&h->lbg, B * h->mb);
     rc |= dalloc(&h->primal, B * h->n); rc |= dalloc(&h->dual, B * h->mb); rc |= dalloc(&h->cost, B); rc |= dalloc(&h->pin_dual, B * nx);
-    rc |= dalloc(&h->kkt, B * 4); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx);
+    rc |= dalloc(&h->kkt, B * 8); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx);
     rc |= dalloc(&h->eta, B * N * N * ni); rc |= dalloc(&h->eta_f, B * (N + 1) * nif); rc |= dalloc(&h->beta, B * N * N * ni);
     rc |= dalloc(&h->beta_f, B * (N + 1) * nif); rc |= dalloc(&h->backoff, B * N * ni); rc |= dalloc(&h->backoff_f, B * nif);
     rc |= dalloc(&h->backoff_x, B * (N + 1) * nx); rc |= dalloc(&h->backoff_u, B * N * nu); rc |= dalloc(&h->K, B * N * (N + 1) * nu * nx);
@@ -139,7 +139,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     reg("backoff_x", h->backoff_x, sizeof(double) * (N + 1) * nx); reg("backoff_u", h->backoff_u, sizeof(double) * N * nu);
     reg("eta", h->eta, sizeof(double) * N * N * ni); reg("eta_f", h->eta_f, sizeof(double) * (N + 1) * nif);
     reg("K", h->K, sizeof(double) * N * (N + 1) * nu * nx); reg("ubg", h->ubg, sizeof(double) * h->mb); reg("lbg", h->lbg, sizeof(double) * h->mb);
-    reg("kkt", h->kkt, sizeof(double) * 4); reg("pin_dual", h->pin_dual, sizeof(double) * nx);
+    reg("kkt", h->kkt, sizeof(double) * 8); reg("pin_dual", h->pin_dual, sizeof(double) * nx);
     return h;
 }
 

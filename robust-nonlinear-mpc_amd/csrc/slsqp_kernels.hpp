@@ -54,7 +54,8 @@ struct QpArgs {
     double *dual;             // (B,mb)
     double *cost;             // (B)
     double *pin_dual;         // (B,NX) multipliers of the x0-pin rows (may be NULL)
-    double *kkt;              // (B,4) stationarity, box violation, dual sign violation, eq residual est.
+    double *kkt;              // (B,8) [0..3] accepted solution: stationarity, box violation, multiplier-sign violation, mu;
+                              //       [4..7] last polish attempt: stationarity, box, sign, factorisation-failed flag
     int *status, *iters;      // (B)
     int max_iter;
     double eps;
@@ -282,9 +283,9 @@ __global__ __launch_bounds__(64) void k_qp(QpArgs a) {
 
     enum { P_INIT = 0, P_PRED = 1, P_CORR = 2, P_POL0 = 3, P_POL1 = 4, P_POL2 = 5, P_DONE = 6 };
     int phase = (status == ST_INIT) ? P_INIT : P_DONE;
-    int it = 0, chol_fail = 0, pol_fail = 0;
+    int it = 0, chol_fail = 0, pol_fail = 0, pol_round = 0;
     double mu = 0.0, res = 0.0, smu = 0.0, alpha = 0.0;
-    double kst = 0.0, kbox = 0.0, ksign = 0.0;
+    double kst = 0.0, kbox = 0.0, ksign = 0.0, pst = -1.0, pbox = -1.0, psign = -1.0;
     bool polished = false;
     unsigned actU = 0u, actL = 0u;   // bit t: element t*64+lane is held at its upper / lower bound by the polish
 
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(64) void k_qp(QpArgs a) {
         const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
         const int f = ne_forward<NX, NU>(c, factor, eflag, phase == P_POL0 ? 1e-10 : 0.0);
         ne_backward<NX, NU>(c);
-        if (phase == P_POL0) pol_fail |= f; else chol_fail |= f;
+        if (phase == P_POL0) pol_fail = f; else chol_fail |= f;
 
         bool start_iter = false;
         if (phase == P_INIT) {
@@ -435,10 +436,36 @@ __global__ __launch_bounds__(64) void k_qp(QpArgs a) {
                 }
                 vst = wla::wave_max(vst); vbox = wla::wave_max(vbox); vsign = wla::wave_max(vsign);
                 const double ptol = 1e-9 * qscale;
+                pst = vst; pbox = vbox; psign = vsign;
                 if (!pol_fail && vst < ptol && vbox < ptol && vsign < ptol) {
                     polished = true; status = 0; kst = vst; kbox = vbox; ksign = vsign;
-                }
-                phase = P_DONE;
+                    phase = P_DONE;
+                } else if (!pol_fail && vst < ptol && pol_round < 6) {
+                    // primal-dual active-set correction: release constraints whose multiplier has the wrong sign,
+                    // add violated bounds, factorise again
+                    pol_round++;
+                    unsigned nU = 0u, nL = 0u;
+#pragma unroll
+                    for (int t = 0; t < TV; t++) {
+                        const int e = t * 64 + lane;
+                        const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                        const double gr = el.pd * cu[t] + el.q + cl[t];
+                        bool aU = (actU >> t) & 1u, aL = (actL >> t) & 1u;
+                        if (aU && gr > ptol) aU = false;
+                        if (aL && -gr > ptol) aL = false;
+                        if (!aU && !aL) {
+                            if (el.fu && cu[t] > el.hi + ptol) aU = true;
+                            else if (el.fl && cu[t] < el.lo - ptol) aL = true;
+                        }
+                        if (aU) nU |= (1u << t);
+                        if (aL) nL |= (1u << t);
+                        const double z0 = aU ? el.hi : (aL ? el.lo : cu[t]);
+                        const double pi = (el.fr && !aU && !aL) ? 1.0 / el.pd : 0.0;
+                        if (e < n) { c.sPi[e] = pi; c.sV[e] = z0 - pi * (el.pd * z0 + el.q); }
+                    }
+                    actU = nU; actL = nL;
+                    phase = P_POL0;
+                } else phase = P_DONE;
             }
         }
 
@@ -528,7 +555,8 @@ __global__ __launch_bounds__(64) void k_qp(QpArgs a) {
         if (ok) a.cost[b] = csum;
         a.status[b] = status;
         a.iters[b] = it;
-        a.kkt[(size_t)b * 4 + 0] = kst; a.kkt[(size_t)b * 4 + 1] = kbox; a.kkt[(size_t)b * 4 + 2] = ksign; a.kkt[(size_t)b * 4 + 3] = mu;
+        double *kk = a.kkt + (size_t)b * 8;
+        kk[0] = kst; kk[1] = kbox; kk[2] = ksign; kk[3] = mu; kk[4] = pst; kk[5] = pbox; kk[6] = psign; kk[7] = (double)pol_fail;
     }
 }
 

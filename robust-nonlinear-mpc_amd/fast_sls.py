@@ -142,7 +142,7 @@ class BatchedFastSLS:
             beta=self.get("beta", (N, N, ni)), beta_f=self.get("beta_f", (N + 1, nif)),
             backoff=self.get("backoff", (N, ni)), backoff_f=self.get("backoff_f", (nif,)),
             backoff_x=self.get("backoff_x", (N + 1, nx)), backoff_u=self.get("backoff_u", (N, nu)),
-            kkt=self.get("kkt", (4,)),
+            kkt=self.get("kkt", (8,)),
         )
         t = self.timing_ms()
         out["t_qp_ms"] = t["qp"]

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the fast-SLS QP path (BASELINE.json: "QP solves/sec (whole node) + ms/MPC-step,
+rockETH N=20 batch=4096").
+
+A "step" is one MPC step of the hot path over one batch of synthetic instances resident in HBM:
+update_dynamics_list + update_linear_cost + fast_SLS.solve in the reference's closed-loop setting for the rocket
+(rti=1, fast_sls_rti_steps=1: 2 QP solves + 1 SLS sweep per instance, expe/main_rocket_robust_closed_loop.py:80-85).
+value = QP solves / s over all ranks (weak scaling: every rank owns its own 4096 instances; the only collective is one
+RCCL all-gather of the resulting first inputs / nominal trajectories at the end).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+FIXTURE = {"rocket": "sweep_rocket_N20_s0.npz", "quadrotor": "sweep_quadrotor_N20_s0.npz", "pendulum": "sweep_pendulum_N10_s0.npz"}
+QP_BYTES = {"rocket": 93656, "quadrotor": 64504, "pendulum": 6112}     # algorithmic bytes per QP solve
+
+
+def cpu_baseline(batch, n_inst, budget_s=25.0):
+    """Reference-class CPU path (oracle: OSQP-class ADMM + polish with upstream default settings, numba-kernel
+    restatement for the sweep), 1 thread, on the first instances of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    m, N = batch["model"], batch["N"]
+    d = O.dims_of(m.nx, m.nu, m.nw, N, m.ni, m.ni_f)
+    done, qps = 0, 0
+    t0 = time.perf_counter()
+    for b in range(n_inst):
+        f = O.OracleFastSLS(d, m.G, m.Gf, m.g, m.gf, batch["E"], m.Q, m.R, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, O.default_settings())
+        f.set_rti_steps(1)
+        f.update_dynamics_list(batch["A"][b], batch["B"][b], batch["E"], list(batch["g"][b]) + [batch["gN"][b]], batch["c"][b])
+        f.update_linear_cost(batch["q"][b])
+        f.solve(batch["x0_arg"][b])
+        done += 1
+        qps += 2
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": qps / dt, "unit": "QP solves/s", "cores": 1, "kind": "port",
+            "sample": f"{done} rocket-class instances x 1 RTI MPC step (2 QP + 1 sweep), OSQP-class restatement with upstream default settings + polish, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--model", default="rocket")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from robust_nonlinear_mpc_amd import BatchedFastSLS, make_batch
+    from robust_nonlinear_mpc_amd.fast_sls import DeviceBatch
+    fixture = os.path.join(ROOT, "tests", "golden", FIXTURE[args.model])
+    B = args.batch
+    batch = make_batch(args.model, fixture, B, seed=1234 + rank)
+    m, N = batch["model"], batch["N"]
+    f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=B, device=local_rank)
+    f.set_rti_steps(m.fast_sls_rti_steps if args.model == "rocket" else 1)
+    dev = DeviceBatch(f, batch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dev.step()
+    barrier()
+    t_qp = t_sw = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dev.step()
+        tm = f.timing_ms()
+        t_qp += tm["qp"]
+        t_sw += tm["sweep"]
+    u0 = dev.fetch_device("primal_vec", (f.n,))[:, m.nx:m.nx + m.nu].contiguous()
+    if world > 1:
+        gathered = [torch.empty_like(u0) for _ in range(world)]
+        dist.all_gather(gathered, u0)           # RCCL over xGMI: collect the first inputs of every instance
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    st = f.get("status", (), np.int32)
+    its = f.get("qp_iters", (), np.int32)
+    qps_per_step = 2 * B            # RTI: QP#1 + QP#2 per instance
+    launches = 2 * args.steps
+    value = qps_per_step * world * args.steps / dt
+    out = {
+        "metric": "QP solves/sec (whole node), rockETH N=20 batch=4096 RTI MPC step", "value": value, "unit": "QP solves/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.model} N={N} batch={B}/GPU, fast-SLS RTI step (rti_steps=1: 2 QP solves + 1 SLS sweep per instance)",
+                   "qp_n": f.n, "qp_m": f.mb + m.nx, "solved_frac": float(np.mean((st == 0) | (st == 4))),
+                   "polished_frac": float(np.mean(st == 0)), "ipm_iters_mean_last_qp": float(its.mean()), "ipm_iters_max_last_qp": int(its.max()),
+                   "tightened_frac": float(np.mean(f.get("backoff_x", (N + 1, m.nx)).max(axis=(1, 2)) > 0))},
+    }
+    if rank == 0:
+        avg_qp_ms = t_qp / launches
+        alg_bytes = QP_BYTES[args.model] * B
+        achieved = alg_bytes / (avg_qp_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_qp", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                           "traffic": None, "avg_launch_ms": avg_qp_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                           "sweep_avg_launch_ms": t_sw / args.steps}
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(batch, 64)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    f.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -208,3 +208,37 @@ class fast_SLS(BatchedFastSLS):
     def solve(self, x0):
         out = super().solve(np.asarray(x0, dtype=float).reshape(1, -1))
         return {k: (v[0] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == 1 else v) for k, v in out.items()}
+
+
+class DeviceBatch:
+    """Device-resident inputs of one batch (torch CUDA tensors used purely as HBM buffers) so that repeated MPC steps do
+    not cross PCIe: update_dynamics / update_linear_cost / solve are called with SLSQP_DEVICE pointers."""
+
+    def __init__(self, solver, batch):
+        import torch
+        self.torch = torch
+        self.f = solver
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        self.A, self.Bm, self.E = t(batch["A"]), t(batch["B"]), t(batch["E"])
+        self.g, self.gN, self.c, self.q, self.x0 = t(batch["g"]), t(batch["gN"]), t(batch["c"]), t(batch["q"]), t(batch["x0_arg"])
+        self.x0_alt = (-self.x0).contiguous()
+        self.nstep = 0
+        torch.cuda.synchronize()
+
+    def step(self):
+        """One MPC step of the hot path: update_dynamics_list + update_linear_cost + solve (RTI: 2 QPs + 1 sweep).
+        The measured state alternates between two values so that consecutive steps differ by more than the 1e-3 of
+        check_convergence_socp: otherwise the reference's leaked convergence state would skip the
+        Riccati sweep and tightening on every step after the first, and the step would not be the full hot path."""
+        f, p = self.f, (lambda x: C.c_void_p(x.data_ptr()))
+        x0 = self.x0 if self.nstep % 2 == 0 else self.x0_alt
+        self.nstep += 1
+        L.check(f.lib.slsqp_update_dynamics(f.h, p(self.A), p(self.Bm), p(self.E), p(self.g), p(self.gN), p(self.c), L.DEVICE))
+        L.check(f.lib.slsqp_update_linear_cost(f.h, p(self.q), L.DEVICE))
+        L.check(f.lib.slsqp_solve(f.h, p(x0), L.DEVICE, C.byref(f.opts)))
+
+    def fetch_device(self, name, shape):
+        out = self.torch.empty((self.f.B,) + tuple(shape), dtype=self.torch.float64, device=self.A.device)
+        L.check(self.f.lib.slsqp_get(self.f.h, name.encode(), C.c_void_p(out.data_ptr()), L.DEVICE))
+        return out

@@ -77,7 +77,7 @@ struct NeCtx {
 //   rhs b_k = E_k v - eflag * e_k, block forward substitution w_k = Linv_k (b_k - L_{k,k-1} w_{k-1}).
 // One call site only (the caller is a phase machine): keeps code size and register pressure down.
 template <int NX, int NU>
-__device__ __noinline__ int ne_forward(NeCtx<NX, NU> &c, bool factor, double eflag, double delta) {
+__device__ __forceinline__ int ne_forward(const NeCtx<NX, NU> c, bool factor, double eflag, double delta) {
     constexpr int NZ = NX + NU, SR = NX + 2 * NZ;
     const int lane = c.lane;
     int fail = 0;
@@ -160,7 +160,7 @@ __device__ __noinline__ int ne_forward(NeCtx<NX, NU> &c, bool factor, double efl
 
 // Backward sweep: nu_k = Linv_k' (w_k - L_{k+1,k}' nu_{k+1}) (overwrites w in sW) and G = E' nu (n-vector in sG).
 template <int NX, int NU>
-__device__ __noinline__ void ne_backward(NeCtx<NX, NU> &c) {
+__device__ __forceinline__ void ne_backward(const NeCtx<NX, NU> c) {
     constexpr int NZ = NX + NU;
     const int lane = c.lane;
     if (lane < NX) c.sT3[lane] = 0.0;  // A_{k+1}' nu_{k+1}

@@ -34,6 +34,12 @@ def load():
     if not os.path.exists(SO_PATH):
         raise RuntimeError(f"{SO_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                            "There is no CPU fallback.")
+    try:
+        # Load torch's HIP runtime first when torch is present: two different libamdhip64 copies in one process
+        # (torch's bundled one and /opt/rocm's) do not mix, and the first one loaded wins.
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(SO_PATH)
     vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p
     lib.slsqp_last_error.restype = C.c_char_p

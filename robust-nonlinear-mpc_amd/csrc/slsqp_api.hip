@@ -40,7 +40,7 @@ struct slsqp_handle {
     double *A, *Bm, *E, *g, *gN, *c, *q, *x0val, *gf_raw, *cst;  // cst: Qd Rd Qfd Qregd Rregd Qregfd packed
     double *ubg, *lbg;
     // results / state
-    double *primal, *dual, *cost, *pin_dual, *kkt, *prev_primal, *Linv;
+    double *primal, *dual, *cost, *pin_dual, *kkt, *prev_primal, *Linv, *ws, *qpstate;
     double *eta, *eta_f, *beta, *beta_f, *backoff, *backoff_f, *backoff_x, *backoff_u, *K;
     int *status, *iters, *itnum, *has_prev, *conv, *alive, *mask, *success, *infeas, *counter;
     // qp-level CSC maps
@@ -98,7 +98,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->x0val, B * nx); rc |= dalloc(&h->gf_raw, (size_t)nif); rc |= dalloc(&h->cst, (size_t)(3 * nx + 2 * nu) * 2);
     rc |= dalloc(&h->ubg, B * h->mb); rc |= dalloc(&h->lbg, B * h->mb);
     rc |= dalloc(&h->primal, B * h->n); rc |= dalloc(&h->dual, B * h->mb); rc |= dalloc(&h->cost, B); rc |= dalloc(&h->pin_dual, B * nx);
-    rc |= dalloc(&h->kkt, B * 8); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx);
+    rc |= dalloc(&h->kkt, B * 8); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx); rc |= dalloc(&h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(&h->qpstate, B * 16);
     rc |= dalloc(&h->eta, B * N * N * ni); rc |= dalloc(&h->eta_f, B * (N + 1) * nif); rc |= dalloc(&h->beta, B * N * N * ni);
     rc |= dalloc(&h->beta_f, B * (N + 1) * nif); rc |= dalloc(&h->backoff, B * N * ni); rc |= dalloc(&h->backoff_f, B * nif);
     rc |= dalloc(&h->backoff_x, B * (N + 1) * nx); rc |= dalloc(&h->backoff_u, B * N * nu); rc |= dalloc(&h->K, B * N * (N + 1) * nu * nx);
@@ -148,7 +148,7 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     hipSetDevice(h->dev);
     hipStreamSynchronize(h->st);
     void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
-                    h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
+                    h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->ws, h->qpstate, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
                     h->backoff_u, h->K, h->status, h->iters, h->itnum, h->has_prev, h->conv, h->alive, h->mask, h->success, h->infeas,
                     h->counter, h->mapA, h->mapB};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -276,32 +276,39 @@ __global__ void k_join_y(int B, int mb, int nx, const double *dual, const double
 }
 
 // ---- kernel dispatch ---------------------------------------------------------------------------------------
-template <int NX, int NU, int TV>
-static int launch_qp_tv(slsqp_handle *h, const QpArgs &a) {
+template <int NX, int NU>
+static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter) {
     const size_t lds = sizeof(double) * qp_lds_doubles<NX, NU>(h->d.N);
-    HIPCHK(hipFuncSetAttribute((const void *)k_qp<NX, NU, TV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_qp<NX, NU, TV>), dim3(h->B), dim3(64), lds, h->st, a);
+    const dim3 grid(h->B), blk(64);
+    HIPCHK(hipMemsetAsync(a.n_active, 0, sizeof(int), h->st));
+    hipLaunchKernelGGL((k_phase<NX, NU>), grid, blk, 0, h->st, a, 1);
+    // every instance needs 1 (start) + 2 per interior-point iteration + 3 per polish round ticks; poll the number of
+    // unfinished instances every few ticks instead of running the worst case
+    const int max_ticks = 1 + 2 * max_iter + 3 * 7 + 2;
+    int tick = 0, active = 1;
+    while (tick < max_ticks && active > 0) {
+        const int burst = tick < 12 ? 12 : 3;
+        for (int i = 0; i < burst; i++, tick++) {
+            hipLaunchKernelGGL((k_ne_fwd<NX, NU>), grid, blk, lds, h->st, a);
+            hipLaunchKernelGGL((k_ne_bwd<NX, NU>), grid, blk, lds, h->st, a);
+            hipLaunchKernelGGL((k_phase<NX, NU>), grid, blk, 0, h->st, a, 0);
+        }
+        HIPCHK(hipMemcpyAsync(&active, a.n_active, sizeof(int), hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+    }
     HIPCHK(hipGetLastError());
     return 0;
-}
-// register tiling TV = ceil(n/64) rounded up to an instantiated value
-template <int NX, int NU, int T0, int T1, int T2>
-static int launch_qp_t(slsqp_handle *h, const QpArgs &a) {
-    const int tv = (h->n + 63) / 64;
-    if (tv <= T0) return launch_qp_tv<NX, NU, T0>(h, a);
-    if (tv <= T1) return launch_qp_tv<NX, NU, T1>(h, a);
-    if (tv <= T2) return launch_qp_tv<NX, NU, T2>(h, a);
-    return fail("horizon too long for the instantiated register tiling");
 }
 
 static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o) {
     QpArgs a;
     a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;
-    a.cst = costs_of(h); a.Linv = h->Linv; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
+    a.cst = costs_of(h); a.Linv = h->Linv; a.ws = h->ws; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
     a.status = h->status; a.iters = h->iters; a.max_iter = o->qp_max_iter; a.eps = o->qp_eps;
-    if (h->d.nx == 4) return launch_qp_t<4, 1, 1, 2, 3>(h, a);
-    if (h->d.nx == 13) return launch_qp_t<13, 4, 3, 6, 9>(h, a);
-    return launch_qp_t<17, 4, 4, 7, 11>(h, a);
+    a.state = h->qpstate; a.n_active = h->counter + 1;
+    if (h->d.nx == 4) return launch_qp_t<4, 1>(h, a, o->qp_max_iter);
+    if (h->d.nx == 13) return launch_qp_t<13, 4>(h, a, o->qp_max_iter);
+    return launch_qp_t<17, 4>(h, a, o->qp_max_iter);
 }
 
 template <int NX, int NU>

@@ -22,6 +22,9 @@ namespace slsqp {
 constexpr double BIGB = 1e19;   // |bound| above this is "infinite" (the reference maps +-inf to +-1e20, qp_jit.py:382)
 constexpr double EPS_PIN = 1e-10;
 constexpr int ST_INIT = -1;
+#ifndef QP_WAVES_PER_SIMD
+#define QP_WAVES_PER_SIMD 2
+#endif
 
 struct Costs {  // batch-constant diagonal weights (device pointers)
     const double *Qd, *Rd, *Qfd;        // diag of Q, R, Qf (P = 2*blkdiag)
@@ -50,6 +53,9 @@ struct QpArgs {
     const int *run;           // (B) 1 = solve this instance (NULL = all)
     Costs cst;
     double *Linv;             // scratch (B,N,NX,NX)
+    double *ws;               // scratch (B, qp_ws_doubles(n,N,NX)): the IPM's n-vectors
+    double *state;            // scratch (B,16): QpState
+    int *n_active;            // number of instances still iterating
     double *primal;           // (B,n)
     double *dual;             // (B,mb)
     double *cost;             // (B)
@@ -61,141 +67,163 @@ struct QpArgs {
     double eps;
 };
 
+// LDS layout of one QP wave: 5 rotating NX x NX buffers (A_k | Y_k | L_{k,k-1} (also B diag(pi_u)) | Linv_{k-1} | M1 -> Linv_k),
+// B_k, and a handful of stage vectors.  Everything of size n (IPM vectors) lives in an HBM/L2 workspace.
 template <int NX, int NU>
-struct NeCtx {
-    static constexpr int NZ = NX + NU;
-    double *sA, *sB, *sBs, *sM1, *sY, *sLa, *sLb, *sL1, *sCol;
-    double *sPi, *sV, *sG, *sW, *sT1, *sT2, *sT3;
-    const double *gA, *gB;        // this instance's A (N,NX,NX), B (N,NX,NU)
-    const double *gUb, *gLb;      // this instance's ubg / lbg rows (eq rhs = centre of the dynamics rows' box)
-    double *gLinv;                // scratch: Linv_k (N,NX,NX)
-    int N, lane;
+struct QpLds {
+    static constexpr int NZ = NX + NU, MM = NX * NX;
+    static constexpr int oA = 0, oY = MM, oL1 = 2 * MM, oP = 3 * MM, oQ = 4 * MM, oB = 5 * MM, oPiS = oB + NX * NU, oVS = oPiS + NZ + NX,
+                         oWp = oVS + NZ + NX, oT1 = oWp + NX, oT2 = oT1 + NX, oT3 = oT2 + NX, oCol = oT3 + NX, TOTAL = oCol + NX + 2;
+};
+template <int NX, int NU>
+__host__ __device__ constexpr int qp_lds_doubles(int) { return QpLds<NX, NU>::TOTAL; }
+
+// workspace arrays per instance (doubles): 12 n-vectors + 3 (N*NX)-vectors
+__host__ __device__ inline size_t qp_ws_doubles(int n, int N, int NX) { return (size_t)12 * n + (size_t)3 * N * NX; }
+
+template <int NX, int NU>
+struct NeG {   // global-memory operands of the sweeps (this instance)
+    const double *A, *Bm, *ub, *lb;
+    double *Linv, *PI, *V, *G, *W;
+    int N;
 };
 
 // Forward sweep over the horizon of the block-tridiagonal normal equations  Y nu = b,  Y = E Pi E':
-//   optional (re)factorisation  L_kk L_kk' = Y_kk - L_{k,k-1} L_{k,k-1}'  (explicit inverse Linv_k kept),
+//   optional (re)factorisation  L_kk L_kk' = Y_kk - L_{k,k-1} L_{k,k-1}'  (explicit inverse Linv_k kept, written to HBM scratch),
 //   rhs b_k = E_k v - eflag * e_k, block forward substitution w_k = Linv_k (b_k - L_{k,k-1} w_{k-1}).
-// One call site only (the caller is a phase machine): keeps code size and register pressure down.
 template <int NX, int NU>
-__device__ __forceinline__ int ne_forward(const NeCtx<NX, NU> c, bool factor, double eflag, double delta) {
-    constexpr int NZ = NX + NU, SR = NX + 2 * NZ;
-    const int lane = c.lane;
+__device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool factor, double eflag, double delta, int lane) {
+    using Ld = QpLds<NX, NU>;
+    constexpr int NZ = NX + NU, SR = NX + 2 * NZ, MM = NX * NX;
+    double *sA = sm + Ld::oA, *sY = sm + Ld::oY, *sL1 = sm + Ld::oL1, *sB = sm + Ld::oB, *sPiS = sm + Ld::oPiS, *sVS = sm + Ld::oVS;
+    double *sWp = sm + Ld::oWp, *sT1 = sm + Ld::oT1, *sT2 = sm + Ld::oT2, *sCol = sm + Ld::oCol;
+    double *Lprev = sm + Ld::oP, *Lcur = sm + Ld::oQ;
     int fail = 0;
-    double *Lcur = c.sLa, *Lprev = c.sLb;
-    for (int k = 0; k < c.N; k++) {
-        const double *Ak = c.gA + (size_t)k * NX * NX, *Bk = c.gB + (size_t)k * NX * NU;
+    // software pipeline: stage k+1's blocks are fetched HBM/L2 -> registers while stage k is being processed
+    constexpr int RA = (MM + 63) / 64, RB = (NX * NU + 63) / 64;
+    double rA[RA], rB[RB], rL[RA], rPi = 0.0, rV = 0.0, rE = 0.0;
+    auto prefetch = [&](int k) {
+        const double *Ak = g.A + (size_t)k * MM, *Bk = g.Bm + (size_t)k * NX * NU, *Lg = g.Linv + (size_t)k * MM;
 #pragma unroll
-        for (int o = lane; o < NX * NX; o += 64) c.sA[o] = Ak[o];
+        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; rA[r] = (o < MM) ? Ak[o] : 0.0; }
 #pragma unroll
-        for (int o = lane; o < NX * NU; o += 64) c.sB[o] = Bk[o];
+        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; rB[r] = (o < NX * NU) ? Bk[o] : 0.0; }
         if (!factor) {
-            const double *Lg = c.gLinv + (size_t)k * NX * NX;
 #pragma unroll
-            for (int o = lane; o < NX * NX; o += 64) Lcur[o] = Lg[o];
+            for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; rL[r] = (o < MM) ? Lg[o] : 0.0; }
         }
-        double ek = 0.0;
-        if (lane < NX && eflag != 0.0) ek = 0.5 * (c.gUb[k * SR + lane] + c.gLb[k * SR + lane]);
+        if (lane < NZ + NX) { rPi = g.PI[k * NZ + lane]; rV = g.V[k * NZ + lane]; }
+        if (lane < NX && eflag != 0.0) rE = 0.5 * (g.ub[k * SR + lane] + g.lb[k * SR + lane]);
+    };
+    prefetch(0);
+    for (int k = 0; k < g.N; k++) {
+#pragma unroll
+        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < MM) sA[o] = rA[r]; }
+#pragma unroll
+        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) sB[o] = rB[r]; }
+        if (!factor) {
+#pragma unroll
+            for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < MM) Lcur[o] = rL[r]; }
+        }
+        if (lane < NZ + NX) { sPiS[lane] = rPi; sVS[lane] = rV; }
+        const double ek = rE;
         wla::wsync();
+        if (k + 1 < g.N) prefetch(k + 1);
         if (factor) {
-            const double *pix = c.sPi + k * NZ, *piu = pix + NX, *pixn = c.sPi + (k + 1) * NZ;
+            // M1 = A diag(pi_x,k) (into Lcur's buffer, dead until the inverse is written)
 #pragma unroll
-            for (int o = lane; o < NX * NX; o += 64) c.sM1[o] = (k > 0) ? c.sA[o] * pix[o % NX] : 0.0;
-#pragma unroll
-            for (int o = lane; o < NX * NU; o += 64) c.sBs[o] = c.sB[o] * piu[o % NU];
+            for (int o = lane; o < MM; o += 64) Lcur[o] = (k > 0) ? sA[o] * sPiS[o % NX] : 0.0;
             wla::wsync();
-            // Y = M1 A' + Bs B' + diag(pi_x,k+1) + delta
-#pragma unroll
-            for (int o0 = 0; o0 < NX * NX; o0 += 64) {
-                const int o = o0 + lane;
-                if (o < NX * NX) {
-                    const int i = o / NX, j = o % NX;
-                    double s = (i == j) ? pixn[i] + delta : 0.0;
-#pragma unroll
-                    for (int m = 0; m < NX; m++) s = fma(c.sM1[i * NX + m], c.sA[j * NX + m], s);
-#pragma unroll
-                    for (int m = 0; m < NU; m++) s = fma(c.sBs[i * NU + m], c.sB[j * NU + m], s);
-                    c.sY[o] = s;
-                }
-            }
-            if (k > 0) wla::gemm<NX, NX, NX, false, true>(c.sM1, NX, Lprev, NX, c.sL1, NX, -1.0, 0.0, lane);  // L_{k,k-1} = -M1 Linv_{k-1}'
-            wla::wsync();
-            if (k > 0) {
-                wla::gemm<NX, NX, NX, false, true>(c.sL1, NX, c.sL1, NX, c.sY, NX, -1.0, 1.0, lane);
+            if (k > 0) {   // L_{k,k-1} = -M1 Linv_{k-1}'
+                wla::gemm_nt_blk<NX, NX, NX, 3, 2>(Lcur, NX, Lprev, NX, sL1, NX, -1.0, lane);
                 wla::wsync();
             }
-            fail |= wla::chol_inv<NX>(c.sY, NX, Lcur, NX, c.sCol, lane);
-            double *Lg = c.gLinv + (size_t)k * NX * NX;
+            // lower(Y) = M1 A' + B diag(pi_u) B' + diag(pi_x,k+1) + delta - L1 L1'
+            wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
+            wla::wsync();
+            fail |= wla::chol_inv<NX>(sY, NX, Lcur, NX, sCol, lane);
+            double *Lg = g.Linv + (size_t)k * MM;
 #pragma unroll
-            for (int o = lane; o < NX * NX; o += 64) Lg[o] = Lcur[o];
+            for (int o = lane; o < MM; o += 64) Lg[o] = Lcur[o];
         }
-        // rhs
-        const double *vx = c.sV + k * NZ, *vu = vx + NX, *vxn = c.sV + (k + 1) * NZ;
+        // rhs b = A v_x + B v_u - v_x,k+1 - eflag e_k  (+ A (pi_x,k .* Linv_{k-1}' w_{k-1}))
         double b = 0.0;
         if (lane < NX) {
-            b = -vxn[lane] - eflag * ek;
+            b = -sVS[NZ + lane] - eflag * ek;
 #pragma unroll
-            for (int m = 0; m < NX; m++) b = fma(c.sA[lane * NX + m], vx[m], b);
+            for (int m = 0; m < NX; m++) b = fma(sA[lane * NX + m], sVS[m], b);
 #pragma unroll
-            for (int m = 0; m < NU; m++) b = fma(c.sB[lane * NU + m], vu[m], b);
+            for (int m = 0; m < NU; m++) b = fma(sB[lane * NU + m], sVS[NX + m], b);
         }
         if (k > 0) {
-            // -L_{k,k-1} w_{k-1} = A_k (pi_x,k .* (Linv_{k-1}' w_{k-1}))
-            const double t = wla::matvec_row<NX, NX, true>(Lprev, NX, c.sW + (k - 1) * NX, lane);
-            if (lane < NX) c.sT1[lane] = t * c.sPi[k * NZ + lane];
+            const double t = wla::matvec_row<NX, NX, true>(Lprev, NX, sWp, lane);
+            if (lane < NX) sT1[lane] = t * sPiS[lane];
             wla::wsync();
             if (lane < NX) {
 #pragma unroll
-                for (int m = 0; m < NX; m++) b = fma(c.sA[lane * NX + m], c.sT1[m], b);
+                for (int m = 0; m < NX; m++) b = fma(sA[lane * NX + m], sT1[m], b);
             }
         }
-        if (lane < NX) c.sT2[lane] = b;
+        if (lane < NX) sT2[lane] = b;
         wla::wsync();
-        const double w = wla::matvec_row<NX, NX, false>(Lcur, NX, c.sT2, lane);
-        if (lane < NX) c.sW[k * NX + lane] = w;
+        const double w = wla::matvec_row<NX, NX, false>(Lcur, NX, sT2, lane);
         wla::wsync();
+        if (lane < NX) { sWp[lane] = w; g.W[k * NX + lane] = w; }
         double *t = Lcur; Lcur = Lprev; Lprev = t;
+        wla::wsync();
     }
     return fail;
 }
 
-// Backward sweep: nu_k = Linv_k' (w_k - L_{k+1,k}' nu_{k+1}) (overwrites w in sW) and G = E' nu (n-vector in sG).
+// Backward sweep: nu_k = Linv_k' (w_k - L_{k+1,k}' nu_{k+1}) (overwrites W) and G = E' nu.
 template <int NX, int NU>
-__device__ __forceinline__ void ne_backward(const NeCtx<NX, NU> c) {
-    constexpr int NZ = NX + NU;
-    const int lane = c.lane;
-    if (lane < NX) c.sT3[lane] = 0.0;  // A_{k+1}' nu_{k+1}
+__device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int lane) {
+    using Ld = QpLds<NX, NU>;
+    constexpr int NZ = NX + NU, MM = NX * NX;
+    double *sA = sm + Ld::oA, *sLa = sm + Ld::oQ, *sB = sm + Ld::oB, *sPiS = sm + Ld::oPiS, *sWp = sm + Ld::oWp;
+    double *sT1 = sm + Ld::oT1, *sT2 = sm + Ld::oT2, *sT3 = sm + Ld::oT3;
+    if (lane < NX) sT3[lane] = 0.0;  // A_{k+1}' nu_{k+1}
     wla::wsync();
-    for (int k = c.N - 1; k >= 0; k--) {
-        const double *Ak = c.gA + (size_t)k * NX * NX, *Bk = c.gB + (size_t)k * NX * NU, *Lg = c.gLinv + (size_t)k * NX * NX;
+    constexpr int RA = (MM + 63) / 64, RB = (NX * NU + 63) / 64;
+    double rA[RA], rB[RB], rL[RA], rPi = 0.0, rW = 0.0;
+    auto prefetch = [&](int k) {
+        const double *Ak = g.A + (size_t)k * MM, *Bk = g.Bm + (size_t)k * NX * NU, *Lg = g.Linv + (size_t)k * MM;
 #pragma unroll
-        for (int o = lane; o < NX * NX; o += 64) { c.sA[o] = Ak[o]; c.sLa[o] = Lg[o]; }
+        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; rA[r] = (o < MM) ? Ak[o] : 0.0; rL[r] = (o < MM) ? Lg[o] : 0.0; }
 #pragma unroll
-        for (int o = lane; o < NX * NU; o += 64) c.sB[o] = Bk[o];
-        if (lane < NX) c.sT1[lane] = c.sPi[(k + 1) * NZ + lane] * c.sT3[lane];
+        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; rB[r] = (o < NX * NU) ? Bk[o] : 0.0; }
+        if (lane < NX) { rPi = g.PI[(k + 1) * NZ + lane]; rW = g.W[k * NX + lane]; }
+    };
+    prefetch(g.N - 1);
+    for (int k = g.N - 1; k >= 0; k--) {
+#pragma unroll
+        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < MM) { sA[o] = rA[r]; sLa[o] = rL[r]; } }
+#pragma unroll
+        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) sB[o] = rB[r]; }
+        if (lane < NX) { sPiS[lane] = rPi; sWp[lane] = rW; }
         wla::wsync();
-        const double tmp = wla::matvec_row<NX, NX, false>(c.sLa, NX, c.sT1, lane);
-        if (lane < NX) c.sT2[lane] = c.sW[k * NX + lane] + tmp;
+        if (k > 0) prefetch(k - 1);
+        if (lane < NX) sT1[lane] = sPiS[lane] * sT3[lane];
         wla::wsync();
-        const double nu = wla::matvec_row<NX, NX, true>(c.sLa, NX, c.sT2, lane);
+        const double tmp = wla::matvec_row<NX, NX, false>(sLa, NX, sT1, lane);
+        if (lane < NX) sT2[lane] = sWp[lane] + tmp;
+        wla::wsync();
+        const double nu = wla::matvec_row<NX, NX, true>(sLa, NX, sT2, lane);
+        wla::wsync();
         if (lane < NX) {
-            c.sW[k * NX + lane] = nu;
-            c.sG[(k + 1) * NZ + lane] = c.sT3[lane] - nu;
+            g.W[k * NX + lane] = nu;
+            g.G[(k + 1) * NZ + lane] = sT3[lane] - nu;
+            sT2[lane] = nu;
         }
         wla::wsync();
-        const double ga = wla::matvec_row<NX, NX, true>(c.sA, NX, c.sW + k * NX, lane);
-        const double gb = wla::matvec_row<NU, NX, true>(c.sB, NU, c.sW + k * NX, lane);
-        if (lane < NX) c.sT3[lane] = ga;
-        if (lane < NU) c.sG[k * NZ + NX + lane] = gb;
+        const double ga = wla::matvec_row<NX, NX, true>(sA, NX, sT2, lane);
+        const double gb = wla::matvec_row<NU, NX, true>(sB, NU, sT2, lane);
+        wla::wsync();
+        if (lane < NX) sT3[lane] = ga;
+        if (lane < NU) g.G[k * NZ + NX + lane] = gb;
         wla::wsync();
     }
-    if (lane < NX) c.sG[lane] = c.sT3[lane];
-    wla::wsync();
-}
-
-template <int NX, int NU>
-__host__ __device__ constexpr int qp_lds_doubles(int N) {
-    // sA sM1 sY sLa sLb sL1 (6 NX^2) + sB sBs (2 NX NU) + sCol,sT1..3 (4 NX) + sPi sV sG (3 n) + sW sNu sNuP (3 N NX)
-    return 6 * NX * NX + 2 * NX * NU + 4 * NX + 3 * ((NX + NU) * N + NX) + 3 * N * NX + 8;
+    if (lane < NX) g.G[lane] = sT3[lane];
 }
 
 // per-element constants of the stage-ordered primal vector, re-read from L2-resident inputs where needed
@@ -204,360 +232,352 @@ template <int NX, int NU>
 __device__ __forceinline__ Elem elem_of(int e, int n, int N, const double *ub, const double *qg, const Costs &cst) {
     constexpr int NZ = NX + NU, SR = NX + 2 * NZ;
     Elem r;
-    r.hi = 1e20; r.lo = -1e20; r.q = 0.0; r.pd = 1.0; r.fu = r.fl = r.fr = false;
-    if (e < n) {
-        const int k = e / NZ, i = e % NZ;
-        r.q = qg[e];
-        if (k < N) {
-            r.pd = 2.0 * (i < NX ? cst.Qd[i] : cst.Rd[i - NX]);
-            r.hi = ub[k * SR + NX + i];
-            r.lo = -ub[k * SR + NX + NZ + i];
-        } else {
-            r.pd = 2.0 * cst.Qfd[i];
-            r.hi = ub[N * SR + i];
-            r.lo = -ub[N * SR + NX + i];
-        }
-        r.fr = e >= NX;
-        r.fu = r.fr && r.hi < BIGB;
-        r.fl = r.fr && r.lo > -BIGB;
+    const int k = e / NZ, i = e % NZ;
+    r.q = qg[e];
+    if (k < N) {
+        r.pd = 2.0 * (i < NX ? cst.Qd[i] : cst.Rd[i - NX]);
+        r.hi = ub[k * SR + NX + i];
+        r.lo = -ub[k * SR + NX + NZ + i];
+    } else {
+        r.pd = 2.0 * cst.Qfd[i];
+        r.hi = ub[N * SR + i];
+        r.lo = -ub[N * SR + NX + i];
     }
+    r.fr = e >= NX;
+    r.fu = r.fr && r.hi < BIGB;
+    r.fl = r.fr && r.lo > -BIGB;
     return r;
 }
 
-// QP kernel.  Algorithm (per instance, one wave):
+// ------------------------------------------------------------------------------------------------
+// QP solver = phase machine over three kernels per "tick" (k_ne_fwd, k_ne_bwd, k_phase), state per instance in HBM.
+// Algorithm (per instance):
 //   1. equality-constrained optimum (bounds ignored) as starting point,
 //   2. Mehrotra predictor-corrector interior point; every Newton system is reduced to the block-tridiagonal
 //      normal equations  (E Pi E') dnu = rhs,  Pi = (P + Sigma)^-1 diagonal, factorised stage by stage,
 //   3. active-set polish (the OSQP-polish idea, qp_jit.py:546 `polishing=True`): fix the variables the interior
 //      point identifies as active, re-solve the KKT system exactly with 2 refinement steps, accept only if the
-//      KKT certificate (stationarity, box feasibility, multiplier signs) holds to 1e-9.
-template <int NX, int NU, int TV>
-__global__ __launch_bounds__(64) void k_qp(QpArgs a) {
+//      KKT certificate (stationarity, box feasibility, multiplier signs) holds to 1e-9; otherwise correct the
+//      active set (primal-dual active-set step) and repeat, at most 6 times.
+// One tick = one block-tridiagonal solve (forward sweep, backward sweep) + the elementwise work that consumes it and
+// prepares the next right-hand side.  Instances advance independently (different phases coexist in one launch);
+// finished instances exit at once.  Splitting the former single kernel removed 340 VGPR + 382 SGPR spills.
+// ------------------------------------------------------------------------------------------------
+enum { P_INIT = 0, P_PRED = 1, P_CORR = 2, P_POL0 = 3, P_POL1 = 4, P_POL2 = 5, P_DONE = 6 };
+struct QpState {   // per instance, 16 doubles
+    double phase, it, status, mu, smu, qscale, mtot, pol_round, pol_fail, chol_fail, kst, kbox, ksign, pst, pbox, psign;
+};
+
+template <int NX, int NU>
+__device__ __forceinline__ NeG<NX, NU> make_neg(const QpArgs &a, int b) {
+    using L = Lay<NX, NU>;
+    const int N = a.N, n = L::n(N), mb = L::mb(N);
+    double *ws = a.ws + (size_t)b * qp_ws_doubles(n, N, NX);
+    NeG<NX, NU> g;
+    g.A = a.A + (size_t)b * N * NX * NX; g.Bm = a.Bm + (size_t)b * N * NX * NU;
+    g.ub = a.ubg + (size_t)b * mb; g.lb = a.lbg + (size_t)b * mb;
+    g.Linv = a.Linv + (size_t)b * N * NX * NX; g.PI = ws + 8 * (size_t)n; g.V = ws + 9 * (size_t)n; g.G = ws + 10 * (size_t)n;
+    g.W = ws + 12 * (size_t)n; g.N = N;
+    return g;
+}
+
+template <int NX, int NU>
+__global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B || (a.run && !a.run[b])) return;
+    QpState *st = (QpState *)a.state + b;
+    const int phase = (int)st->phase;
+    if (phase == P_DONE) return;
+    extern __shared__ double sm[];
+    const bool factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
+    const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
+    const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane);
+    if (lane == 0 && factor) { if (phase == P_POL0) st->pol_fail = f; else if (f) st->chol_fail = 1.0; }
+}
+
+template <int NX, int NU>
+__global__ __launch_bounds__(64) void k_ne_bwd(QpArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B || (a.run && !a.run[b])) return;
+    const QpState *st = (const QpState *)a.state + b;
+    if ((int)st->phase == P_DONE) return;
+    extern __shared__ double sm[];
+    ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
+}
+
+// first = 1: set up the instance (x0-pin check, starting rhs); else consume the solve of the current phase.
+template <int NX, int NU>
+__global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
     using L = Lay<NX, NU>;
     constexpr int NZ = L::NZ, SR = L::SR;
     const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B) return;
-    if (a.run && !a.run[b]) return;
+    if (b >= a.B || (a.run && !a.run[b])) return;
     const int N = a.N, n = L::n(N), mb = L::mb(N);
-    extern __shared__ double sm[];
-    NeCtx<NX, NU> c;
-    double *p = sm;
-    c.sA = p; p += NX * NX; c.sM1 = p; p += NX * NX; c.sY = p; p += NX * NX; c.sLa = p; p += NX * NX;
-    c.sLb = p; p += NX * NX; c.sL1 = p; p += NX * NX; c.sB = p; p += NX * NU; c.sBs = p; p += NX * NU;
-    c.sCol = p; p += NX; c.sT1 = p; p += NX; c.sT2 = p; p += NX; c.sT3 = p; p += NX;
-    c.sPi = p; p += n; c.sV = p; p += n; c.sG = p; p += n;
-    c.sW = p; p += N * NX; double *sNu = p; p += N * NX; double *sNuP = p; p += N * NX;
-    c.gA = a.A + (size_t)b * N * NX * NX; c.gB = a.Bm + (size_t)b * N * NX * NU; c.gLinv = a.Linv + (size_t)b * N * NX * NX;
-    const double *ub = a.ubg + (size_t)b * mb, *lb = a.lbg + (size_t)b * mb, *qg = a.q + (size_t)b * n;
-    c.gUb = ub; c.gLb = lb; c.N = N; c.lane = lane;
+    const double *ub = a.ubg + (size_t)b * mb, *qg = a.q + (size_t)b * n;
+    double *ws = a.ws + (size_t)b * qp_ws_doubles(n, N, NX);
+    double *Z = ws, *SU = Z + n, *SL = SU + n, *LU = SL + n, *LL = LU + n, *GC = LL + n, *CU = GC + n, *CL = CU + n;
+    double *PI = CL + n, *V = PI + n, *G = V + n, *ACT = G + n, *W = ACT + n, *NUA = W + N * NX, *NUP = NUA + N * NX;
     const Costs cst = a.cst;
+    QpState *stp = (QpState *)a.state + b;
 
-    int status = ST_INIT;
-    {   // x0 pin vs its own box (the reference applies both the pin rows and the stage-0 inequality rows)
-        double viol = 0.0;
+    if (first) {
+        int status = ST_INIT;
+        double viol = 0.0;   // x0 pin vs its own box (the reference applies both the pin rows and the stage-0 inequality rows)
         if (lane < NX) {
             const double xv = a.x0val[(size_t)b * NX + lane];
             viol = fmax(xv - ub[NX + lane], -ub[NX + NZ + lane] - xv);
         }
         if (wla::wave_max(viol) > 1e-9) status = 2;
+        double qscale = 0.0, mtot = 0.0;
+        for (int e = lane; e < n; e += 64) {
+            const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+            qscale = fmax(qscale, fabs(el.q));
+            mtot += (el.fu ? 1.0 : 0.0) + (el.fl ? 1.0 : 0.0);
+            const double z0 = (e < NX) ? a.x0val[(size_t)b * NX + e] : 0.0;   // rhs of P_INIT: v = z0 - Pi (P z0 + q), z0 = [x0;0]
+            const double pi = el.fr ? 1.0 / el.pd : 0.0;
+            PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q); Z[e] = z0;
+        }
+        qscale = fmax(1.0, wla::wave_max(qscale));
+        mtot = fmax(1.0, wla::wave_sum(mtot));
+        if (lane == 0) {
+            QpState s0;
+            s0.phase = (status == ST_INIT) ? P_INIT : P_DONE; s0.it = 0; s0.status = status; s0.mu = 0; s0.smu = 0; s0.qscale = qscale;
+            s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.chol_fail = 0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1;
+            *stp = s0;
+            a.status[b] = status; a.iters[b] = 0;
+            if (status == ST_INIT) atomicAdd(a.n_active, 1);
+        }
+        return;
     }
-    double z[TV], su[TV], sl[TV], lu[TV], ll[TV], gc[TV], cu[TV], cl[TV];
-    double qscale = 0.0, mtot = 0.0;
-#pragma unroll
-    for (int t = 0; t < TV; t++) {
-        const int e = t * 64 + lane;
-        const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-        qscale = fmax(qscale, fabs(el.q));
-        mtot += (el.fu ? 1.0 : 0.0) + (el.fl ? 1.0 : 0.0);
-        // phase INIT rhs: v = z0 - Pi (P z0 + q) with z0 = [x0; 0]
-        const double z0 = (e < NX) ? a.x0val[(size_t)b * NX + e] : 0.0;
-        const double pi = el.fr ? 1.0 / el.pd : 0.0;
-        if (e < n) { c.sPi[e] = pi; c.sV[e] = z0 - pi * (el.pd * z0 + el.q); }
-        z[t] = z0; su[t] = sl[t] = 1.0; lu[t] = ll[t] = 0.0; gc[t] = 0.0; cu[t] = cl[t] = 0.0;
-    }
-    qscale = fmax(1.0, wla::wave_max(qscale));
-    mtot = fmax(1.0, wla::wave_sum(mtot));
-    const double tol = a.eps * qscale;
-    for (int o = lane; o < N * NX; o += 64) { sNu[o] = 0.0; sNuP[o] = 0.0; }
-    wla::wsync();
 
-    enum { P_INIT = 0, P_PRED = 1, P_CORR = 2, P_POL0 = 3, P_POL1 = 4, P_POL2 = 5, P_DONE = 6 };
-    int phase = (status == ST_INIT) ? P_INIT : P_DONE;
-    int it = 0, chol_fail = 0, pol_fail = 0, pol_round = 0;
-    double mu = 0.0, res = 0.0, smu = 0.0, alpha = 0.0;
-    double kst = 0.0, kbox = 0.0, ksign = 0.0, pst = -1.0, pbox = -1.0, psign = -1.0;
-    bool polished = false;
-    unsigned actU = 0u, actL = 0u;   // bit t: element t*64+lane is held at its upper / lower bound by the polish
+    QpState s = *stp;
+    int phase = (int)s.phase;
+    if (phase == P_DONE) return;
+    int status = (int)s.status, it = (int)s.it;
+    const double qscale = s.qscale, mtot = s.mtot, tol = a.eps * qscale, ptol = 1e-9 * qscale;
+    bool polished = false, start_iter = false;
 
-    while (phase != P_DONE) {
-        const bool factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
-        const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
-        const int f = ne_forward<NX, NU>(c, factor, eflag, phase == P_POL0 ? 1e-10 : 0.0);
-        ne_backward<NX, NU>(c);
-        if (phase == P_POL0) pol_fail = f; else chol_fail |= f;
-
-        bool start_iter = false;
-        if (phase == P_INIT) {
-            for (int o = lane; o < N * NX; o += 64) sNu[o] = c.sW[o];
-#pragma unroll
-            for (int t = 0; t < TV; t++) {
-                const int e = t * 64 + lane;
-                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                if (e < n) {
-                    gc[t] = c.sG[e];
-                    if (el.fr) z[t] = -(el.q + gc[t]) / el.pd;
-                    if (el.fu) { su[t] = fmax(el.hi - z[t], 1.0); lu[t] = 1.0; }
-                    if (el.fl) { sl[t] = fmax(z[t] - el.lo, 1.0); ll[t] = 1.0; }
-                }
+    if (phase == P_INIT) {
+        for (int o = lane; o < N * NX; o += 64) NUA[o] = W[o];
+        for (int e = lane; e < n; e += 64) {
+            const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+            const double gc = G[e];
+            const double z = el.fr ? -(el.q + gc) / el.pd : Z[e];
+            GC[e] = gc; Z[e] = z;
+            SU[e] = el.fu ? fmax(el.hi - z, 1.0) : 1.0; LU[e] = el.fu ? 1.0 : 0.0;
+            SL[e] = el.fl ? fmax(z - el.lo, 1.0) : 1.0; LL[e] = el.fl ? 1.0 : 0.0;
+        }
+        start_iter = true;
+    } else if (phase == P_PRED) {
+        // affine step: step length, mu_aff = (S0 + a S1 + a^2 S2)/m, second-order terms ds*dlambda
+        double amin = 1.0, S0 = 0.0, S1 = 0.0, S2 = 0.0;
+        for (int e = lane; e < n; e += 64) {
+            const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+            const double dz = V[e] - PI[e] * G[e];
+            const double z = Z[e], su = SU[e], sl = SL[e], lu = LU[e], ll = LL[e];
+            double cu = 0.0, cl = 0.0;
+            if (el.fu) {
+                const double ru = z + su - el.hi, dsu = -ru - dz, dlu = -lu + (lu * ru + lu * dz) / su;
+                if (dsu < 0) amin = fmin(amin, -su / dsu);
+                if (dlu < 0) amin = fmin(amin, -lu / dlu);
+                S0 += su * lu; S1 += su * dlu + lu * dsu; cu = dsu * dlu; S2 += cu;
             }
-            start_iter = true;
-        } else if (phase == P_PRED) {
-            // affine step -> centring parameter -> corrector rhs
-            double amin = 1.0;
-#pragma unroll
-            for (int t = 0; t < TV; t++) {
-                const int e = t * 64 + lane;
-                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                const double dz = (e < n) ? c.sV[e] - c.sPi[e] * c.sG[e] : 0.0;
-                const double ru = el.fu ? z[t] + su[t] - el.hi : 0.0, rl = el.fl ? el.lo - z[t] + sl[t] : 0.0;
-                const double Wu = el.fu ? lu[t] / su[t] : 0.0, Wl = el.fl ? ll[t] / sl[t] : 0.0;
-                const double tu = el.fu ? (-su[t] * lu[t] + lu[t] * ru) / su[t] : 0.0;
-                const double tl = el.fl ? (-sl[t] * ll[t] + ll[t] * rl) / sl[t] : 0.0;
-                const double dsu = el.fu ? -ru - dz : 0.0, dsl = el.fl ? -rl + dz : 0.0;
-                const double dlu = tu + Wu * dz, dll = tl - Wl * dz;
-                if (el.fu) { if (dsu < 0) amin = fmin(amin, -su[t] / dsu); if (dlu < 0) amin = fmin(amin, -lu[t] / dlu); }
-                if (el.fl) { if (dsl < 0) amin = fmin(amin, -sl[t] / dsl); if (dll < 0) amin = fmin(amin, -ll[t] / dll); }
-                cu[t] = dsu; cl[t] = dsl;       // hold the affine slack steps; multiplied by dlambda below
-                gc[t] += 0.0;
-                // stash dlu/dll in sG/sV? -> recompute below from dz (cheap)
+            if (el.fl) {
+                const double rl = el.lo - z + sl, dsl = -rl + dz, dll = -ll + (ll * rl - ll * dz) / sl;
+                if (dsl < 0) amin = fmin(amin, -sl / dsl);
+                if (dll < 0) amin = fmin(amin, -ll / dll);
+                S0 += sl * ll; S1 += sl * dll + ll * dsl; cl = dsl * dll; S2 += cl;
             }
-            const double aaff = wla::wave_min(amin);
-            double s1 = 0.0;
-#pragma unroll
-            for (int t = 0; t < TV; t++) {
-                const int e = t * 64 + lane;
-                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                const double dz = (e < n) ? c.sV[e] - c.sPi[e] * c.sG[e] : 0.0;
-                const double ru = el.fu ? z[t] + su[t] - el.hi : 0.0, rl = el.fl ? el.lo - z[t] + sl[t] : 0.0;
-                const double Wu = el.fu ? lu[t] / su[t] : 0.0, Wl = el.fl ? ll[t] / sl[t] : 0.0;
-                const double tu = el.fu ? (-su[t] * lu[t] + lu[t] * ru) / su[t] : 0.0;
-                const double tl = el.fl ? (-sl[t] * ll[t] + ll[t] * rl) / sl[t] : 0.0;
-                const double dlu = tu + Wu * dz, dll = tl - Wl * dz;
-                s1 += (el.fu ? (su[t] + aaff * cu[t]) * (lu[t] + aaff * dlu) : 0.0) + (el.fl ? (sl[t] + aaff * cl[t]) * (ll[t] + aaff * dll) : 0.0);
-                cu[t] *= dlu; cl[t] *= dll;     // second-order terms ds*dlambda
+            CU[e] = cu; CL[e] = cl;
+        }
+        const double aaff = wla::wave_min(amin);
+        S0 = wla::wave_sum(S0); S1 = wla::wave_sum(S1); S2 = wla::wave_sum(S2);
+        const double muaff = (S0 + aaff * (S1 + aaff * S2)) / mtot;
+        double sig = muaff / s.mu; sig = sig * sig * sig;
+        const double smu = sig * s.mu;
+        s.smu = smu;
+        for (int e = lane; e < n; e += 64) {
+            const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+            const double z = Z[e], su = SU[e], sl = SL[e], lu = LU[e], ll = LL[e];
+            double rr = el.fr ? el.pd * z + el.q + GC[e] + lu - ll : 0.0;
+            if (el.fu) rr += (-(su * lu + CU[e] - smu) + lu * (z + su - el.hi)) / su;
+            if (el.fl) rr -= (-(sl * ll + CL[e] - smu) + ll * (el.lo - z + sl)) / sl;
+            V[e] = -PI[e] * rr;
+        }
+        phase = P_CORR;
+    } else if (phase == P_CORR) {
+        const double smu = s.smu;
+        double amin = 1e300;
+        for (int e = lane; e < n; e += 64) {
+            const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+            const double dz = V[e] - PI[e] * G[e];
+            const double z = Z[e], su = SU[e], sl = SL[e], lu = LU[e], ll = LL[e];
+            if (el.fu) {
+                const double ru = z + su - el.hi, dsu = -ru - dz;
+                const double dlu = (-(su * lu + CU[e] - smu) + lu * ru + lu * dz) / su;
+                if (dsu < 0) amin = fmin(amin, -su / dsu);
+                if (dlu < 0) amin = fmin(amin, -lu / dlu);
             }
-            const double muaff = wla::wave_sum(s1) / mtot;
-            double sig = muaff / mu; sig = sig * sig * sig;
-            smu = sig * mu;
-            wla::wsync();
-#pragma unroll
-            for (int t = 0; t < TV; t++) {
-                const int e = t * 64 + lane;
-                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                const double ru = el.fu ? z[t] + su[t] - el.hi : 0.0, rl = el.fl ? el.lo - z[t] + sl[t] : 0.0;
-                const double rd = el.fr ? el.pd * z[t] + el.q + gc[t] + lu[t] - ll[t] : 0.0;
-                const double tu = el.fu ? (-(su[t] * lu[t] + cu[t] - smu) + lu[t] * ru) / su[t] : 0.0;
-                const double tl = el.fl ? (-(sl[t] * ll[t] + cl[t] - smu) + ll[t] * rl) / sl[t] : 0.0;
-                if (e < n) c.sV[e] = -c.sPi[e] * (rd + tu - tl);
-            }
-            phase = P_CORR;
-        } else if (phase == P_CORR) {
-            double amin = 1e300;
-#pragma unroll
-            for (int t = 0; t < TV; t++) {
-                const int e = t * 64 + lane;
-                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                const double dz = (e < n) ? c.sV[e] - c.sPi[e] * c.sG[e] : 0.0;
-                const double ru = el.fu ? z[t] + su[t] - el.hi : 0.0, rl = el.fl ? el.lo - z[t] + sl[t] : 0.0;
-                const double Wu = el.fu ? lu[t] / su[t] : 0.0, Wl = el.fl ? ll[t] / sl[t] : 0.0;
-                const double tu = el.fu ? (-(su[t] * lu[t] + cu[t] - smu) + lu[t] * ru) / su[t] : 0.0;
-                const double tl = el.fl ? (-(sl[t] * ll[t] + cl[t] - smu) + ll[t] * rl) / sl[t] : 0.0;
-                const double dsu = el.fu ? -ru - dz : 0.0, dsl = el.fl ? -rl + dz : 0.0;
-                const double dlu = tu + Wu * dz, dll = tl - Wl * dz;
-                if (el.fu) { if (dsu < 0) amin = fmin(amin, -su[t] / dsu); if (dlu < 0) amin = fmin(amin, -lu[t] / dlu); }
-                if (el.fl) { if (dsl < 0) amin = fmin(amin, -sl[t] / dsl); if (dll < 0) amin = fmin(amin, -ll[t] / dll); }
-            }
-            alpha = fmin(1.0, 0.99 * wla::wave_min(amin));
-#pragma unroll
-            for (int t = 0; t < TV; t++) {
-                const int e = t * 64 + lane;
-                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                const double g = (e < n) ? c.sG[e] : 0.0;
-                const double dz = (e < n) ? c.sV[e] - c.sPi[e] * g : 0.0;
-                const double ru = el.fu ? z[t] + su[t] - el.hi : 0.0, rl = el.fl ? el.lo - z[t] + sl[t] : 0.0;
-                const double Wu = el.fu ? lu[t] / su[t] : 0.0, Wl = el.fl ? ll[t] / sl[t] : 0.0;
-                const double tu = el.fu ? (-(su[t] * lu[t] + cu[t] - smu) + lu[t] * ru) / su[t] : 0.0;
-                const double tl = el.fl ? (-(sl[t] * ll[t] + cl[t] - smu) + ll[t] * rl) / sl[t] : 0.0;
-                const double dsu = el.fu ? -ru - dz : 0.0, dsl = el.fl ? -rl + dz : 0.0;
-                const double dlu = tu + Wu * dz, dll = tl - Wl * dz;
-                z[t] += alpha * dz; gc[t] += alpha * g;
-                if (el.fu) { su[t] += alpha * dsu; lu[t] += alpha * dlu; }
-                if (el.fl) { sl[t] += alpha * dsl; ll[t] += alpha * dll; }
-            }
-            for (int o = lane; o < N * NX; o += 64) sNu[o] += alpha * c.sW[o];
-            it++;
-            start_iter = true;
-        } else {
-            // polish phases: zn = v - Pi g  (v was z0 - Pi r or zn - Pi r1), accumulate g and nu
-#pragma unroll
-            for (int t = 0; t < TV; t++) {
-                const int e = t * 64 + lane;
-                const double g = (e < n) ? c.sG[e] : 0.0;
-                cu[t] = (e < n) ? c.sV[e] - c.sPi[e] * g : 0.0;   // cu := zn
-                cl[t] = (phase == P_POL0 ? 0.0 : cl[t]) + g;        // cl := accumulated E' nu
-            }
-            for (int o = lane; o < N * NX; o += 64) sNuP[o] = (phase == P_POL0 ? 0.0 : sNuP[o]) + c.sW[o];
-            wla::wsync();
-            if (phase != P_POL2) {
-#pragma unroll
-                for (int t = 0; t < TV; t++) {
-                    const int e = t * 64 + lane;
-                    const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                    if (e < n) {
-                        const double pi = c.sPi[e];
-                        const double r1 = (pi != 0.0) ? el.pd * cu[t] + el.q + cl[t] : 0.0;
-                        c.sV[e] = cu[t] - pi * r1;
-                    }
-                }
-                phase = phase + 1;
-            } else {
-                double vst = 0.0, vbox = 0.0, vsign = 0.0;
-#pragma unroll
-                for (int t = 0; t < TV; t++) {
-                    const int e = t * 64 + lane;
-                    const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                    const double gr = el.pd * cu[t] + el.q + cl[t];
-                    const bool aU = (actU >> t) & 1u, aL = (actL >> t) & 1u;
-                    if (el.fr && !aU && !aL) vst = fmax(vst, fabs(gr));
-                    if (el.fu) vbox = fmax(vbox, cu[t] - el.hi);
-                    if (el.fl) vbox = fmax(vbox, el.lo - cu[t]);
-                    if (aU) vsign = fmax(vsign, gr);    // lambda_u = -gr must be >= 0
-                    if (aL) vsign = fmax(vsign, -gr);   // lambda_l = +gr must be >= 0
-                }
-                vst = wla::wave_max(vst); vbox = wla::wave_max(vbox); vsign = wla::wave_max(vsign);
-                const double ptol = 1e-9 * qscale;
-                pst = vst; pbox = vbox; psign = vsign;
-                if (!pol_fail && vst < ptol && vbox < ptol && vsign < ptol) {
-                    polished = true; status = 0; kst = vst; kbox = vbox; ksign = vsign;
-                    phase = P_DONE;
-                } else if (!pol_fail && vst < ptol && pol_round < 6) {
-                    // primal-dual active-set correction: release constraints whose multiplier has the wrong sign,
-                    // add violated bounds, factorise again
-                    pol_round++;
-                    unsigned nU = 0u, nL = 0u;
-#pragma unroll
-                    for (int t = 0; t < TV; t++) {
-                        const int e = t * 64 + lane;
-                        const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                        const double gr = el.pd * cu[t] + el.q + cl[t];
-                        bool aU = (actU >> t) & 1u, aL = (actL >> t) & 1u;
-                        if (aU && gr > ptol) aU = false;
-                        if (aL && -gr > ptol) aL = false;
-                        if (!aU && !aL) {
-                            if (el.fu && cu[t] > el.hi + ptol) aU = true;
-                            else if (el.fl && cu[t] < el.lo - ptol) aL = true;
-                        }
-                        if (aU) nU |= (1u << t);
-                        if (aL) nL |= (1u << t);
-                        const double z0 = aU ? el.hi : (aL ? el.lo : cu[t]);
-                        const double pi = (el.fr && !aU && !aL) ? 1.0 / el.pd : 0.0;
-                        if (e < n) { c.sPi[e] = pi; c.sV[e] = z0 - pi * (el.pd * z0 + el.q); }
-                    }
-                    actU = nU; actL = nL;
-                    phase = P_POL0;
-                } else phase = P_DONE;
+            if (el.fl) {
+                const double rl = el.lo - z + sl, dsl = -rl + dz;
+                const double dll = (-(sl * ll + CL[e] - smu) + ll * rl - ll * dz) / sl;
+                if (dsl < 0) amin = fmin(amin, -sl / dsl);
+                if (dll < 0) amin = fmin(amin, -ll / dll);
             }
         }
-
-        if (start_iter) {
-            // residuals, complementarity, termination test; then either predictor rhs or polish rhs
-            double rmax = 0.0, musum = 0.0;
-#pragma unroll
-            for (int t = 0; t < TV; t++) {
-                const int e = t * 64 + lane;
-                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                const double rd = el.fr ? el.pd * z[t] + el.q + gc[t] + lu[t] - ll[t] : 0.0;
-                const double ru = el.fu ? z[t] + su[t] - el.hi : 0.0, rl = el.fl ? el.lo - z[t] + sl[t] : 0.0;
-                rmax = fmax(rmax, fmax(fabs(rd), fmax(fabs(ru), fabs(rl))));
-                musum += (el.fu ? su[t] * lu[t] : 0.0) + (el.fl ? sl[t] * ll[t] : 0.0);
+        const double alpha = fmin(1.0, 0.99 * wla::wave_min(amin));
+        for (int e = lane; e < n; e += 64) {
+            const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+            const double gg = G[e];
+            const double dz = V[e] - PI[e] * gg;
+            const double z = Z[e], su = SU[e], sl = SL[e], lu = LU[e], ll = LL[e];
+            if (el.fu) {
+                const double ru = z + su - el.hi, dsu = -ru - dz;
+                const double dlu = (-(su * lu + CU[e] - smu) + lu * ru + lu * dz) / su;
+                SU[e] = su + alpha * dsu; LU[e] = lu + alpha * dlu;
             }
-            res = wla::wave_max(rmax);
-            mu = wla::wave_sum(musum) / mtot;
-            kst = res;
-            wla::wsync();
-            if (!(res == res) || !(mu == mu) || res > 1e30) { status = 3; phase = P_DONE; }
-            else if (res < tol && mu < tol) {
-                status = 4;
-                // polish rhs: active set, z0 with active entries on their bounds, Pi = 0 there
-                actU = 0u; actL = 0u;
-#pragma unroll
-                for (int t = 0; t < TV; t++) {
-                    const int e = t * 64 + lane;
+            if (el.fl) {
+                const double rl = el.lo - z + sl, dsl = -rl + dz;
+                const double dll = (-(sl * ll + CL[e] - smu) + ll * rl - ll * dz) / sl;
+                SL[e] = sl + alpha * dsl; LL[e] = ll + alpha * dll;
+            }
+            Z[e] = z + alpha * dz; GC[e] += alpha * gg;
+        }
+        for (int o = lane; o < N * NX; o += 64) NUA[o] += alpha * W[o];
+        it++;
+        start_iter = true;
+    } else {
+        // polish phases: zn = v - Pi g  (v was z0 - Pi r or zn - Pi r1); CU := zn, CL := accumulated E' nu
+        const bool firstp = (phase == P_POL0);
+        for (int e = lane; e < n; e += 64) {
+            const double gg = G[e];
+            CU[e] = V[e] - PI[e] * gg;
+            CL[e] = (firstp ? 0.0 : CL[e]) + gg;
+        }
+        for (int o = lane; o < N * NX; o += 64) NUP[o] = (firstp ? 0.0 : NUP[o]) + W[o];
+        wla::wsync_mem();
+        if (phase != P_POL2) {
+            for (int e = lane; e < n; e += 64) {
+                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                const double pi = PI[e], zn = CU[e];
+                const double r1 = (pi != 0.0) ? el.pd * zn + el.q + CL[e] : 0.0;
+                V[e] = zn - pi * r1;
+            }
+            phase = phase + 1;
+        } else {
+            double vst = 0.0, vbox = 0.0, vsign = 0.0;
+            for (int e = lane; e < n; e += 64) {
+                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                const double zn = CU[e], gr = el.pd * zn + el.q + CL[e], ac = ACT[e];
+                if (el.fr && ac == 0.0) vst = fmax(vst, fabs(gr));
+                if (el.fu) vbox = fmax(vbox, zn - el.hi);
+                if (el.fl) vbox = fmax(vbox, el.lo - zn);
+                if (ac > 0.0) vsign = fmax(vsign, gr);     // lambda_u = -gr must be >= 0
+                if (ac < 0.0) vsign = fmax(vsign, -gr);    // lambda_l = +gr must be >= 0
+            }
+            vst = wla::wave_max(vst); vbox = wla::wave_max(vbox); vsign = wla::wave_max(vsign);
+            s.pst = vst; s.pbox = vbox; s.psign = vsign;
+            const bool pf = s.pol_fail != 0.0;
+            if (!pf && vst < ptol && vbox < ptol && vsign < ptol) {
+                polished = true; status = 0; s.kst = vst; s.kbox = vbox; s.ksign = vsign;
+                phase = P_DONE;
+            } else if (!pf && vst < ptol && s.pol_round < 6.0) {
+                // primal-dual active-set correction: release constraints whose multiplier has the wrong sign,
+                // add violated bounds, factorise again
+                s.pol_round += 1.0;
+                for (int e = lane; e < n; e += 64) {
                     const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                    const double lam = lu[t] - ll[t];
-                    const bool aU = el.fu && (lam > el.hi - z[t]);
-                    const bool aL = el.fl && !aU && (-lam > z[t] - el.lo);
-                    if (aU) actU |= (1u << t);
-                    if (aL) actL |= (1u << t);
-                    const double z0 = aU ? el.hi : (aL ? el.lo : z[t]);
-                    const double pi = (el.fr && !aU && !aL) ? 1.0 / el.pd : 0.0;
-                    if (e < n) { c.sPi[e] = pi; c.sV[e] = z0 - pi * (el.pd * z0 + el.q); }
+                    const double zn = CU[e], gr = el.pd * zn + el.q + CL[e];
+                    double ac = ACT[e];
+                    if (ac > 0.0 && gr > ptol) ac = 0.0;
+                    if (ac < 0.0 && -gr > ptol) ac = 0.0;
+                    if (ac == 0.0) {
+                        if (el.fu && zn > el.hi + ptol) ac = 1.0;
+                        else if (el.fl && zn < el.lo - ptol) ac = -1.0;
+                    }
+                    const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zn);
+                    const double pi = (el.fr && ac == 0.0) ? 1.0 / el.pd : 0.0;
+                    ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
                 }
                 phase = P_POL0;
-            } else if (it >= a.max_iter) { status = 1; phase = P_DONE; }
-            else {
-#pragma unroll
-                for (int t = 0; t < TV; t++) {
-                    const int e = t * 64 + lane;
-                    const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                    const double rd = el.fr ? el.pd * z[t] + el.q + gc[t] + lu[t] - ll[t] : 0.0;
-                    const double ru = el.fu ? z[t] + su[t] - el.hi : 0.0, rl = el.fl ? el.lo - z[t] + sl[t] : 0.0;
-                    const double Wu = el.fu ? lu[t] / su[t] : 0.0, Wl = el.fl ? ll[t] / sl[t] : 0.0;
-                    const double pi = el.fr ? 1.0 / (el.pd + Wu + Wl) : 0.0;
-                    const double tu = el.fu ? (-su[t] * lu[t] + lu[t] * ru) / su[t] : 0.0;
-                    const double tl = el.fl ? (-sl[t] * ll[t] + ll[t] * rl) / sl[t] : 0.0;
-                    if (e < n) { c.sPi[e] = pi; c.sV[e] = -pi * (rd + tu - tl); }
-                }
-                phase = P_PRED;
-            }
+            } else phase = P_DONE;
         }
-        wla::wsync();
     }
 
-    // ---- write-out (reference layouts: primal qp_jit.py:489-490, duals :493-501) ----
-    double *pr = a.primal + (size_t)b * n, *du = a.dual + (size_t)b * mb;
-    double csum = 0.0;
-    const bool ok = (status == 0 || status == 4);   // on failure the previous primal/dual stay (fast_SLS_jit.py:461-464)
-#pragma unroll
-    for (int t = 0; t < TV; t++) {
-        const int e = t * 64 + lane;
-        if (e < n && ok) {
+    if (start_iter) {
+        wla::wsync_mem();
+        // residuals, complementarity, termination test; predictor rhs written in the same pass
+        double rmax = 0.0, musum = 0.0;
+        for (int e = lane; e < n; e += 64) {
             const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-            double zv = z[t], yu = el.fu ? lu[t] : 0.0, yl = el.fl ? ll[t] : 0.0, gv = gc[t];
-            if (polished) {
-                zv = cu[t]; gv = cl[t];
-                const double gr = el.pd * zv + el.q + gv;
-                yu = ((actU >> t) & 1u) ? fmax(-gr, 0.0) : 0.0;
-                yl = ((actL >> t) & 1u) ? fmax(gr, 0.0) : 0.0;
+            const double z = Z[e], su = SU[e], sl = SL[e], lu = LU[e], ll = LL[e];
+            const double rd = el.fr ? el.pd * z + el.q + GC[e] + lu - ll : 0.0;
+            const double ru = el.fu ? z + su - el.hi : 0.0, rl = el.fl ? el.lo - z + sl : 0.0;
+            rmax = fmax(rmax, fmax(fabs(rd), fmax(fabs(ru), fabs(rl))));
+            musum += (el.fu ? su * lu : 0.0) + (el.fl ? sl * ll : 0.0);
+            const double Wu = el.fu ? lu / su : 0.0, Wl = el.fl ? ll / sl : 0.0;
+            const double pi = el.fr ? 1.0 / (el.pd + Wu + Wl) : 0.0;
+            const double tu = el.fu ? -lu + Wu * ru : 0.0, tl = el.fl ? -ll + Wl * rl : 0.0;
+            PI[e] = pi; V[e] = -pi * (rd + tu - tl);
+        }
+        const double res = wla::wave_max(rmax);
+        const double mu = wla::wave_sum(musum) / mtot;
+        s.mu = mu; s.kst = res;
+        if (!(res == res) || !(mu == mu) || res > 1e30) { status = 3; phase = P_DONE; }
+        else if (res < tol && mu < tol) {
+            status = 4;
+            // polish rhs: active set, z0 with active entries on their bounds, Pi = 0 there
+            for (int e = lane; e < n; e += 64) {
+                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                const double z = Z[e], lam = LU[e] - LL[e];
+                const bool aU = el.fu && (lam > el.hi - z);
+                const bool aL = el.fl && !aU && (-lam > z - el.lo);
+                const double z0 = aU ? el.hi : (aL ? el.lo : z);
+                const double pi = (el.fr && !aU && !aL) ? 1.0 / el.pd : 0.0;
+                ACT[e] = aU ? 1.0 : (aL ? -1.0 : 0.0); PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
             }
-            pr[e] = zv;
-            csum += 0.5 * el.pd * zv * zv + el.q * zv;
-            const int k = e / NZ, i = e % NZ;
-            if (k < N) { du[k * SR + NX + i] = yu; du[k * SR + NX + NZ + i] = yl; }
-            else { du[N * SR + i] = yu; du[N * SR + NX + i] = yl; }
-            if (e < NX && a.pin_dual) a.pin_dual[(size_t)b * NX + e] = -(el.pd * zv + el.q + gv);
+            phase = P_POL0;
+        } else if (it >= a.max_iter) { status = 1; phase = P_DONE; }
+        else phase = P_PRED;
+    }
+
+    if (phase == P_DONE) {
+        wla::wsync_mem();
+        // ---- write-out (reference layouts: primal qp_jit.py:489-490, duals :493-501) ----
+        double *pr = a.primal + (size_t)b * n, *du = a.dual + (size_t)b * mb;
+        double csum = 0.0;
+        const bool ok = (status == 0 || status == 4);   // on failure the previous primal/dual stay (fast_SLS_jit.py:461-464)
+        if (ok) {
+            for (int e = lane; e < n; e += 64) {
+                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                double zv, yu, yl, gv;
+                if (polished) {
+                    zv = CU[e]; gv = CL[e];
+                    const double gr = el.pd * zv + el.q + gv, ac = ACT[e];
+                    yu = ac > 0.0 ? fmax(-gr, 0.0) : 0.0;
+                    yl = ac < 0.0 ? fmax(gr, 0.0) : 0.0;
+                } else { zv = Z[e]; gv = GC[e]; yu = el.fu ? LU[e] : 0.0; yl = el.fl ? LL[e] : 0.0; }
+                pr[e] = zv;
+                csum += 0.5 * el.pd * zv * zv + el.q * zv;
+                const int k = e / NZ, i = e % NZ;
+                if (k < N) { du[k * SR + NX + i] = yu; du[k * SR + NX + NZ + i] = yl; }
+                else { du[N * SR + i] = yu; du[N * SR + NX + i] = yl; }
+                if (e < NX && a.pin_dual) a.pin_dual[(size_t)b * NX + e] = -(el.pd * zv + el.q + gv);
+            }
+            const double *nus = polished ? NUP : NUA;
+            for (int o = lane; o < N * NX; o += 64) du[(o / NX) * SR + (o % NX)] = nus[o];
+        }
+        csum = wla::wave_sum(csum);
+        if (lane == 0) {
+            if (ok) a.cost[b] = csum;
+            a.status[b] = status;
+            a.iters[b] = it;
+            double *kk = a.kkt + (size_t)b * 8;
+            kk[0] = s.kst; kk[1] = s.kbox; kk[2] = s.ksign; kk[3] = s.mu; kk[4] = s.pst; kk[5] = s.pbox; kk[6] = s.psign; kk[7] = s.pol_fail;
+            atomicAdd(a.n_active, -1);
         }
     }
-    if (ok) { const double *nus = polished ? sNuP : sNu; for (int o = lane; o < N * NX; o += 64) du[(o / NX) * SR + (o % NX)] = nus[o]; }
-    csum = wla::wave_sum(csum);
-    (void)chol_fail;  // clamped pivots are tolerated when the certificate holds
-    if (lane == 0) {
-        if (ok) a.cost[b] = csum;
-        a.status[b] = status;
-        a.iters[b] = it;
-        double *kk = a.kkt + (size_t)b * 8;
-        kk[0] = kst; kk[1] = kbox; kk[2] = ksign; kk[3] = mu; kk[4] = pst; kk[5] = pbox; kk[6] = psign; kk[7] = (double)pol_fail;
-    }
+    if (lane == 0) { s.phase = phase; s.it = it; s.status = status; *stp = s; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -727,6 +747,7 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
         }
         wla::wsync();
     }
+    wla::wsync_mem();   // K written above is re-read below by other lanes of this wave
     // propagate column j and accumulate row norms
     const double *Eg = a.E + (a.E_per_instance ? (size_t)b * (N + 1) * NX * NW : 0) + (size_t)j * NX * NW;
 #pragma unroll

@@ -10,7 +10,13 @@
 
 namespace wla {
 
-__device__ __forceinline__ void wsync() { __syncthreads(); }
+// LDS-only ordering between lanes of the (single) wave of a workgroup.  NOT __syncthreads(): its workgroup fence
+// also waits for every outstanding global load/store (vmcnt(0)), which cost ~86 % of the wave's lifetime in the first
+// profile.  LDS instructions of one wave execute in order, so waiting for lgkmcnt(0) and stopping the compiler from
+// moving memory operations across this point is all that is needed.
+__device__ __forceinline__ void wsync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Full version for hand-offs through global memory between lanes of the wave (phase boundaries only).
+__device__ __forceinline__ void wsync_mem() { __threadfence_block(); __syncthreads(); }
 
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -58,6 +64,87 @@ __device__ __forceinline__ void gemm(const double *A, int lda, const double *B, 
     }
 }
 
+
+// C(MxN) = alpha * A(MxK) * B(NxK)' with RBxCB register blocking per lane (one pass, needs ceil(M/RB)*ceil(N/CB) <= 64).
+// Out-of-range rows/cols are clamped on load and masked on store.
+template <int M, int N, int K, int RB, int CB>
+__device__ __forceinline__ void gemm_nt_blk(const double *A, int lda, const double *B, int ldb, double *C, int ldc, double alpha, int lane) {
+    constexpr int TR = (M + RB - 1) / RB, TC = (N + CB - 1) / CB;
+    static_assert(TR * TC <= 64, "one pass only");
+    if (lane < TR * TC) {
+        const int tr = lane / TC, tc = lane % TC;
+        int ri[RB], cj[CB];
+#pragma unroll
+        for (int r = 0; r < RB; r++) ri[r] = min(tr * RB + r, M - 1);
+#pragma unroll
+        for (int q = 0; q < CB; q++) cj[q] = min(tc * CB + q, N - 1);
+        double acc[RB][CB];
+#pragma unroll
+        for (int r = 0; r < RB; r++)
+#pragma unroll
+            for (int q = 0; q < CB; q++) acc[r][q] = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            double a[RB], b[CB];
+#pragma unroll
+            for (int r = 0; r < RB; r++) a[r] = A[ri[r] * lda + k];
+#pragma unroll
+            for (int q = 0; q < CB; q++) b[q] = B[cj[q] * ldb + k];
+#pragma unroll
+            for (int r = 0; r < RB; r++)
+#pragma unroll
+                for (int q = 0; q < CB; q++) acc[r][q] = fma(a[r], b[q], acc[r][q]);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; r++)
+#pragma unroll
+            for (int q = 0; q < CB; q++)
+                if (tr * RB + r < M && tc * CB + q < N) C[(tr * RB + r) * ldc + tc * CB + q] = alpha * acc[r][q];
+    }
+}
+
+// Lower triangle (i >= j) of  Y = M1 A' + B diag(piu) B' - L1 L1' + diag(d) ,  all NX x NX (B: NX x NU), 2x2 blocks, one pass.
+// useL1 = false drops the L1 term.  Only the lower triangle of Y is written (the Cholesky reads nothing else).
+template <int NX, int NU>
+__device__ __forceinline__ void build_Y_lower(const double *M1, const double *A, const double *B, const double *piu, const double *L1,
+                                              bool useL1, const double *d, double delta, double *Y, int lane) {
+    constexpr int T = (NX + 1) / 2, NT = T * (T + 1) / 2;
+    static_assert(NT <= 64, "one pass only");
+    if (lane < NT) {
+        // lane -> (bi >= bj) in the lower-triangular block grid
+        int bi = 0, rem = lane;
+        while (rem > bi) { rem -= bi + 1; bi++; }
+        const int bj = rem;
+        const int i0 = bi * 2, i1 = min(i0 + 1, NX - 1), j0 = bj * 2, j1 = min(j0 + 1, NX - 1);
+        double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const double x0 = M1[i0 * NX + k], x1 = M1[i1 * NX + k], y0 = A[j0 * NX + k], y1 = A[j1 * NX + k];
+            a00 = fma(x0, y0, a00); a01 = fma(x0, y1, a01); a10 = fma(x1, y0, a10); a11 = fma(x1, y1, a11);
+        }
+#pragma unroll
+        for (int k = 0; k < NU; k++) {
+            const double pk = piu[k];
+            const double x0 = B[i0 * NU + k] * pk, x1 = B[i1 * NU + k] * pk, y0 = B[j0 * NU + k], y1 = B[j1 * NU + k];
+            a00 = fma(x0, y0, a00); a01 = fma(x0, y1, a01); a10 = fma(x1, y0, a10); a11 = fma(x1, y1, a11);
+        }
+        if (useL1) {
+#pragma unroll
+            for (int k = 0; k < NX; k++) {
+                const double x0 = L1[i0 * NX + k], x1 = L1[i1 * NX + k], y0 = L1[j0 * NX + k], y1 = L1[j1 * NX + k];
+                a00 = fma(-x0, y0, a00); a01 = fma(-x0, y1, a01); a10 = fma(-x1, y0, a10); a11 = fma(-x1, y1, a11);
+            }
+        }
+        if (bi == bj) { a00 += d[i0] + delta; if (i0 + 1 < NX) a11 += d[i0 + 1] + delta; }
+        Y[i0 * NX + j0] = a00;
+        if (j0 + 1 < NX && i0 >= j0 + 1) Y[i0 * NX + j0 + 1] = a01;
+        if (i0 + 1 < NX) {
+            Y[(i0 + 1) * NX + j0] = a10;
+            if (j0 + 1 < NX) Y[(i0 + 1) * NX + j0 + 1] = a11;
+        }
+    }
+}
+
 // y(M) = op(A)(MxK) x(K)  (lane i < M computes row i).  TA: A stored KxM.
 template <int M, int K, bool TA>
 __device__ __forceinline__ double matvec_row(const double *A, int lda, const double *x, int lane) {
@@ -77,7 +164,7 @@ __device__ __forceinline__ int chol_inv(double *Y, int ld, double *Linv, int ldi
     double row[M];
     const bool act = lane < M;
 #pragma unroll
-    for (int c = 0; c < M; c++) row[c] = act ? Y[(act ? lane : 0) * ld + c] : 0.0;
+    for (int c = 0; c < M; c++) row[c] = (act && c <= lane) ? Y[lane * ld + c] : 0.0;
     int fail = 0;
 #pragma unroll
     for (int j = 0; j < M; j++) {

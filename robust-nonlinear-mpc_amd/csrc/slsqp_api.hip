@@ -29,7 +29,7 @@ extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
     o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-8; o->conv_tol = 1e-3;
-    o->eps_backoff = 1e-10; o->want_K = 1;
+    o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 3;
 }
 
 struct slsqp_handle {
@@ -300,12 +300,12 @@ static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter) {
     return 0;
 }
 
-static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o) {
+static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm) {
     QpArgs a;
     a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;
     a.cst = costs_of(h); a.Linv = h->Linv; a.ws = h->ws; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
     a.status = h->status; a.iters = h->iters; a.max_iter = o->qp_max_iter; a.eps = o->qp_eps;
-    a.state = h->qpstate; a.n_active = h->counter + 1;
+    a.state = h->qpstate; a.n_active = h->counter + 1; a.warm = warm; a.warm_rounds = o->warm_rounds;
     if (h->d.nx == 4) return launch_qp_t<4, 1>(h, a, o->qp_max_iter);
     if (h->d.nx == 13) return launch_qp_t<13, 4>(h, a, o->qp_max_iter);
     return launch_qp_t<17, 4>(h, a, o->qp_max_iter);
@@ -358,7 +358,7 @@ extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const sls
     double acc_qp = 0, acc_sw = 0;
     for (int i = 0; i < steps; i++) {
         HIPCHK(hipEventRecord(h->ev[1], h->st));
-        if (launch_qp(h, h->alive, &o)) return -1;
+        if (launch_qp(h, h->alive, &o, (i > 0 || o.warm_start) ? 1 : 0)) return -1;
         HIPCHK(hipEventRecord(h->ev[2], h->st));
         hipLaunchKernelGGL(k_post_qp, dim3(gb), dim3(256), 0, h->st, B, h->status, h->alive, h->infeas);
         EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff};
@@ -380,7 +380,7 @@ extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const sls
     }
     // final QP: RTI always (fast_SLS_jit.py:293); converge mode only for instances that hit MAX_ITER (:311)
     HIPCHK(hipEventRecord(h->ev[1], h->st));
-    if (launch_qp(h, h->alive, &o)) return -1;
+    if (launch_qp(h, h->alive, &o, 1)) return -1;
     HIPCHK(hipEventRecord(h->ev[2], h->st));
     hipLaunchKernelGGL(k_finish, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->alive, h->infeas, h->success);
     HIPCHK(hipEventRecord(h->ev[5], h->st));
@@ -480,7 +480,7 @@ extern "C" int slsqp_qp_solve(slsqp_handle *h, double *x, double *y, int *status
     slsqp_opts o;
     if (opts) o = *opts; else slsqp_default_opts(&o);
     HIPCHK(hipEventRecord(h->ev[0], h->st));
-    if (launch_qp(h, nullptr, &o)) return -1;
+    if (launch_qp(h, nullptr, &o, o.warm_start ? 1 : 0)) return -1;
     HIPCHK(hipEventRecord(h->ev[1], h->st));
     HIPCHK(hipStreamSynchronize(h->st));
     h->t_total = h->t_qp = ev_ms(h->ev[0], h->ev[1]); h->t_sweep = 0;

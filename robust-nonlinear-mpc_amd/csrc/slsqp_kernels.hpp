@@ -65,6 +65,8 @@ struct QpArgs {
     int *status, *iters;      // (B)
     int max_iter;
     double eps;
+    int warm_rounds;          // active-set correction rounds allowed in a warm attempt before falling back
+    int warm;                 // 1: try an active-set polish from the previous solution of each instance first
 };
 
 // LDS layout of one QP wave: 5 rotating NX x NX buffers (A_k | Y_k | L_{k,k-1} (also B diag(pi_u)) | Linv_{k-1} | M1 -> Linv_k),
@@ -89,10 +91,19 @@ struct NeG {   // global-memory operands of the sweeps (this instance)
 };
 
 // Forward sweep over the horizon of the block-tridiagonal normal equations  Y nu = b,  Y = E Pi E':
-//   optional (re)factorisation  L_kk L_kk' = Y_kk - L_{k,k-1} L_{k,k-1}'  (explicit inverse Linv_k kept, written to HBM scratch),
-//   rhs b_k = E_k v - eflag * e_k, block forward substitution w_k = Linv_k (b_k - L_{k,k-1} w_{k-1}).
+//   optional (re)factorisation, block LDL':  D_k = Y_kk - O_k D_{k-1}^-1 O_k',  O_k = Y_{k,k-1} = -A_k diag(pi_x,k)
+//   (explicit symmetric inverses Dinv_k kept, written to HBM scratch),
+//   rhs b_k = E_k v - eflag * e_k, forward elimination t_k = b_k - O_k u_{k-1},  u_k = Dinv_k t_k  (u_k stored in W).
+#ifdef NE_STAMP
+#define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc_[i] += t_ - last_; last_ = t_; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 template <int NX, int NU>
-__device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool factor, double eflag, double delta, int lane) {
+__device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool factor, double eflag, double delta, int lane, long long *dbg = nullptr) {
+#ifdef NE_STAMP
+    long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
     using Ld = QpLds<NX, NU>;
     constexpr int NZ = NX + NU, SR = NX + 2 * NZ, MM = NX * NX;
     double *sA = sm + Ld::oA, *sY = sm + Ld::oY, *sL1 = sm + Ld::oL1, *sB = sm + Ld::oB, *sPiS = sm + Ld::oPiS, *sVS = sm + Ld::oVS;
@@ -128,23 +139,29 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
         if (lane < NZ + NX) { sPiS[lane] = rPi; sVS[lane] = rV; }
         const double ek = rE;
         wla::wsync();
+        STAMP(0);
         if (k + 1 < g.N) prefetch(k + 1);
         if (factor) {
             // M1 = A diag(pi_x,k) (into Lcur's buffer, dead until the inverse is written)
 #pragma unroll
             for (int o = lane; o < MM; o += 64) Lcur[o] = (k > 0) ? sA[o] * sPiS[o % NX] : 0.0;
             wla::wsync();
-            if (k > 0) {   // L_{k,k-1} = -M1 Linv_{k-1}'
-                wla::gemm_nt_blk<NX, NX, NX, 3, 2>(Lcur, NX, Lprev, NX, sL1, NX, -1.0, lane);
+            STAMP(1);
+            if (k > 0) {   // T = M1 Dinv_{k-1}   (Dinv symmetric, so the NT product is the NN one)
+                wla::gemm_nt_blk<NX, NX, NX, 3, 2>(Lcur, NX, Lprev, NX, sL1, NX, 1.0, lane);
                 wla::wsync();
             }
-            // lower(Y) = M1 A' + B diag(pi_u) B' + diag(pi_x,k+1) + delta - L1 L1'
+            STAMP(2);
+            // lower(D_k) = M1 A' + B diag(pi_u) B' + diag(pi_x,k+1) + delta - T M1'      (block LDL': D_k = Y_kk - O D_{k-1}^-1 O')
             wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
             wla::wsync();
-            fail |= wla::chol_inv<NX>(sY, NX, Lcur, NX, sCol, lane);
+            STAMP(3);
+            fail |= wla::spd_inv_gj<NX>(sY, NX, Lcur, NX, sCol, lane);
+            STAMP(4);
             double *Lg = g.Linv + (size_t)k * MM;
 #pragma unroll
             for (int o = lane; o < MM; o += 64) Lg[o] = Lcur[o];
+            STAMP(5);
         }
         // rhs b = A v_x + B v_u - v_x,k+1 - eflag e_k  (+ A (pi_x,k .* Linv_{k-1}' w_{k-1}))
         double b = 0.0;
@@ -155,9 +172,8 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
 #pragma unroll
             for (int m = 0; m < NU; m++) b = fma(sB[lane * NU + m], sVS[NX + m], b);
         }
-        if (k > 0) {
-            const double t = wla::matvec_row<NX, NX, true>(Lprev, NX, sWp, lane);
-            if (lane < NX) sT1[lane] = t * sPiS[lane];
+        if (k > 0) {   // t_k = b_k - O_k u_{k-1} = b_k + A_k (pi_x,k .* u_{k-1}),  u_{k-1} = Dinv_{k-1} t_{k-1} (kept in sWp)
+            if (lane < NX) sT1[lane] = sWp[lane] * sPiS[lane];
             wla::wsync();
             if (lane < NX) {
 #pragma unroll
@@ -166,16 +182,20 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
         }
         if (lane < NX) sT2[lane] = b;
         wla::wsync();
-        const double w = wla::matvec_row<NX, NX, false>(Lcur, NX, sT2, lane);
+        const double w = wla::matvec_row<NX, NX, false>(Lcur, NX, sT2, lane);   // u_k = Dinv_k t_k
         wla::wsync();
         if (lane < NX) { sWp[lane] = w; g.W[k * NX + lane] = w; }
         double *t = Lcur; Lcur = Lprev; Lprev = t;
         wla::wsync();
+        STAMP(6);
     }
+#ifdef NE_STAMP
+    if (dbg && lane == 0) for (int i = 0; i < 8; i++) dbg[i] = acc_[i];
+#endif
     return fail;
 }
 
-// Backward sweep: nu_k = Linv_k' (w_k - L_{k+1,k}' nu_{k+1}) (overwrites W) and G = E' nu.
+// Backward sweep: nu_k = u_k - Dinv_k O_{k+1}' nu_{k+1} (overwrites W) and G = E' nu.
 template <int NX, int NU>
 __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int lane) {
     using Ld = QpLds<NX, NU>;
@@ -205,10 +225,8 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
         if (k > 0) prefetch(k - 1);
         if (lane < NX) sT1[lane] = sPiS[lane] * sT3[lane];
         wla::wsync();
-        const double tmp = wla::matvec_row<NX, NX, false>(sLa, NX, sT1, lane);
-        if (lane < NX) sT2[lane] = sWp[lane] + tmp;
-        wla::wsync();
-        const double nu = wla::matvec_row<NX, NX, true>(sLa, NX, sT2, lane);
+        // nu_k = u_k - Dinv_k O_{k+1}' nu_{k+1} = u_k + Dinv_k (pi_x,k+1 .* A_{k+1}' nu_{k+1})
+        const double nu = sWp[lane < NX ? lane : 0] + wla::matvec_row<NX, NX, false>(sLa, NX, sT1, lane);
         wla::wsync();
         if (lane < NX) {
             g.W[k * NX + lane] = nu;
@@ -265,7 +283,7 @@ __device__ __forceinline__ Elem elem_of(int e, int n, int N, const double *ub, c
 // ------------------------------------------------------------------------------------------------
 enum { P_INIT = 0, P_PRED = 1, P_CORR = 2, P_POL0 = 3, P_POL1 = 4, P_POL2 = 5, P_DONE = 6 };
 struct QpState {   // per instance, 16 doubles
-    double phase, it, status, mu, smu, qscale, mtot, pol_round, pol_fail, chol_fail, kst, kbox, ksign, pst, pbox, psign;
+    double phase, it, status, mu, smu, qscale, mtot, pol_round, pol_fail, warm, kst, kbox, ksign, pst, pbox, psign;
 };
 
 template <int NX, int NU>
@@ -291,8 +309,9 @@ __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
     extern __shared__ double sm[];
     const bool factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
     const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
-    const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane);
-    if (lane == 0 && factor) { if (phase == P_POL0) st->pol_fail = f; else if (f) st->chol_fail = 1.0; }
+    const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane,
+                                     (long long *)(a.kkt + (size_t)b * 8));
+    if (lane == 0 && factor && phase == P_POL0) st->pol_fail = f;
 }
 
 template <int NX, int NU>
@@ -328,21 +347,33 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
             viol = fmax(xv - ub[NX + lane], -ub[NX + NZ + lane] - xv);
         }
         if (wla::wave_max(viol) > 1e-9) status = 2;
+        // warm start: the previous solve of this instance ended with a certified active set -> polish from it first
+        const bool warm = a.warm && ((int)stp->status == 0) && ((int)stp->phase == P_DONE) && status == ST_INIT;
+        const double *prev = a.primal + (size_t)b * n;
         double qscale = 0.0, mtot = 0.0;
         for (int e = lane; e < n; e += 64) {
             const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
             qscale = fmax(qscale, fabs(el.q));
             mtot += (el.fu ? 1.0 : 0.0) + (el.fl ? 1.0 : 0.0);
-            const double z0 = (e < NX) ? a.x0val[(size_t)b * NX + e] : 0.0;   // rhs of P_INIT: v = z0 - Pi (P z0 + q), z0 = [x0;0]
-            const double pi = el.fr ? 1.0 / el.pd : 0.0;
-            PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q); Z[e] = z0;
+            if (warm) {
+                double ac = ACT[e];
+                if ((ac > 0.0 && !el.fu) || (ac < 0.0 && !el.fl) || !el.fr) ac = 0.0;
+                const double zp = (e < NX) ? a.x0val[(size_t)b * NX + e] : prev[e];
+                const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zp);
+                const double pi = (el.fr && ac == 0.0) ? 1.0 / el.pd : 0.0;
+                ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
+            } else {
+                const double z0 = (e < NX) ? a.x0val[(size_t)b * NX + e] : 0.0;   // rhs of P_INIT: v = z0 - Pi (P z0 + q), z0 = [x0;0]
+                const double pi = el.fr ? 1.0 / el.pd : 0.0;
+                PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q); Z[e] = z0;
+            }
         }
         qscale = fmax(1.0, wla::wave_max(qscale));
         mtot = fmax(1.0, wla::wave_sum(mtot));
         if (lane == 0) {
             QpState s0;
-            s0.phase = (status == ST_INIT) ? P_INIT : P_DONE; s0.it = 0; s0.status = status; s0.mu = 0; s0.smu = 0; s0.qscale = qscale;
-            s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.chol_fail = 0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1;
+            s0.phase = (status == ST_INIT) ? (warm ? P_POL0 : P_INIT) : P_DONE; s0.it = 0; s0.status = status; s0.mu = 0; s0.smu = 0; s0.qscale = qscale;
+            s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
             if (status == ST_INIT) atomicAdd(a.n_active, 1);
@@ -481,7 +512,7 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
             if (!pf && vst < ptol && vbox < ptol && vsign < ptol) {
                 polished = true; status = 0; s.kst = vst; s.kbox = vbox; s.ksign = vsign;
                 phase = P_DONE;
-            } else if (!pf && vst < ptol && s.pol_round < 6.0) {
+            } else if (!pf && vst < ptol && s.pol_round < (s.warm != 0.0 ? (double)a.warm_rounds : 6.0)) {
                 // primal-dual active-set correction: release constraints whose multiplier has the wrong sign,
                 // add violated bounds, factorise again
                 s.pol_round += 1.0;
@@ -500,6 +531,16 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
                     ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
                 }
                 phase = P_POL0;
+            } else if (s.warm != 0.0) {
+                // warm attempt failed: cold start of the interior point (rhs of P_INIT)
+                s.warm = 0.0; s.pol_round = 0.0; s.pol_fail = 0.0;
+                for (int e = lane; e < n; e += 64) {
+                    const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                    const double z0 = (e < NX) ? a.x0val[(size_t)b * NX + e] : 0.0;
+                    const double pi = el.fr ? 1.0 / el.pd : 0.0;
+                    PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q); Z[e] = z0;
+                }
+                phase = P_INIT;
             } else phase = P_DONE;
         }
     }
@@ -572,8 +613,10 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
             if (ok) a.cost[b] = csum;
             a.status[b] = status;
             a.iters[b] = it;
+#ifndef NE_STAMP
             double *kk = a.kkt + (size_t)b * 8;
             kk[0] = s.kst; kk[1] = s.kbox; kk[2] = s.ksign; kk[3] = s.mu; kk[4] = s.pst; kk[5] = s.pbox; kk[6] = s.psign; kk[7] = s.pol_fail;
+#endif
             atomicAdd(a.n_active, -1);
         }
     }

@@ -103,11 +103,11 @@ __device__ __forceinline__ void gemm_nt_blk(const double *A, int lda, const doub
     }
 }
 
-// Lower triangle (i >= j) of  Y = M1 A' + B diag(piu) B' - L1 L1' + diag(d) ,  all NX x NX (B: NX x NU), 2x2 blocks, one pass.
-// useL1 = false drops the L1 term.  Only the lower triangle of Y is written (the Cholesky reads nothing else).
+// Lower triangle (i >= j) of  Y = M1 A' + B diag(piu) B' - T M1' + diag(d) ,  all NX x NX (B: NX x NU), 2x2 blocks, one pass.
+// useT = false drops the T term.  Only the lower triangle of Y is written (the Cholesky reads nothing else).
 template <int NX, int NU>
-__device__ __forceinline__ void build_Y_lower(const double *M1, const double *A, const double *B, const double *piu, const double *L1,
-                                              bool useL1, const double *d, double delta, double *Y, int lane) {
+__device__ __forceinline__ void build_Y_lower(const double *M1, const double *A, const double *B, const double *piu, const double *Tm,
+                                              bool useT, const double *d, double delta, double *Y, int lane) {
     constexpr int T = (NX + 1) / 2, NT = T * (T + 1) / 2;
     static_assert(NT <= 64, "one pass only");
     if (lane < NT) {
@@ -128,10 +128,10 @@ __device__ __forceinline__ void build_Y_lower(const double *M1, const double *A,
             const double x0 = B[i0 * NU + k] * pk, x1 = B[i1 * NU + k] * pk, y0 = B[j0 * NU + k], y1 = B[j1 * NU + k];
             a00 = fma(x0, y0, a00); a01 = fma(x0, y1, a01); a10 = fma(x1, y0, a10); a11 = fma(x1, y1, a11);
         }
-        if (useL1) {
+        if (useT) {   // - T M1'  (T = M1 Dinv_prev; the product is symmetric)
 #pragma unroll
             for (int k = 0; k < NX; k++) {
-                const double x0 = L1[i0 * NX + k], x1 = L1[i1 * NX + k], y0 = L1[j0 * NX + k], y1 = L1[j1 * NX + k];
+                const double x0 = Tm[i0 * NX + k], x1 = Tm[i1 * NX + k], y0 = M1[j0 * NX + k], y1 = M1[j1 * NX + k];
                 a00 = fma(-x0, y0, a00); a01 = fma(-x0, y1, a01); a10 = fma(-x1, y0, a10); a11 = fma(-x1, y1, a11);
             }
         }
@@ -156,50 +156,127 @@ __device__ __forceinline__ double matvec_row(const double *A, int lda, const dou
     return s;
 }
 
-// In-place lower Cholesky of the MxM SPD matrix Y (LDS, ld), then Linv = L^{-1} (full MxM, upper part zero).
-// Row i of Y lives in lane i's registers during the factorisation; column j is broadcast through `col`
-// (LDS, >= M doubles).  Returns non-zero (wave-uniform) if a pivot was not positive (pivot clamped).
+// v_rcp_f64 / v_rsq_f64 seeds + two Newton steps: ~1 ulp, a dependent chain of ~8 instructions instead of the ~30 of the
+// correctly rounded division / sqrt sequences (the factorisation below is latency-bound on exactly these chains).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsq(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    r = r * fma(-h * r, r, 1.5);
+    r = r * fma(-h * r, r, 1.5);
+    return r;
+}
+// broadcast lane `l` (compile-time / wave-uniform) of a double through SGPRs: no LDS, no waitcnt
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+
+// Inverse of the MxM SPD matrix Y (lower triangle in LDS) by the symmetric Gauss-Jordan sweep, distributed 2-D over the wave:
+// lane (bi >= bj) owns the 2x2 block rows {2bi,2bi+1} x cols {2bj,2bj+1} of the lower triangle in registers; per pivot j the
+// pivot column is exchanged through `col` (LDS, M+2 doubles) and every lane does 4 FMAs.  17 short steps on 45 lanes instead
+// of 17 long ones on 17 lanes (the row-per-lane Cholesky + triangular inverse this replaces).  Dinv: full symmetric MxM in LDS.
+// Returns non-zero (wave-uniform) if a pivot was not positive (pivot clamped).
+// arbitrary-lane gather of a double through the LDS crossbar (ds_bpermute_b32 x2): no LDS memory, no write+wait round trip
+__device__ __forceinline__ double bperm_d(double v, int src_lane) {
+    const int a = src_lane << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(a, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(a, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 template <int M>
-__device__ __forceinline__ int chol_inv(double *Y, int ld, double *Linv, int ldi, double *col, int lane) {
-    double row[M];
+__device__ __forceinline__ int spd_inv_gj(const double *Y, int ld, double *Dinv, int ldi, double * /*col*/, int lane) {
+    constexpr int T = (M + 1) / 2, NT = T * (T + 1) / 2;
+    static_assert(NT <= 64, "one wave");
+    int bi = 0, rem = min(lane, NT - 1);
+    while (rem > bi) { rem -= bi + 1; bi++; }
+    const int bj = rem;
+    const bool act = lane < NT;
+    const int i0 = 2 * bi, i1 = i0 + 1, l0 = 2 * bj, l1 = l0 + 1;
+    // padded (2T x 2T) matrix: identity in the padding row/col when M is odd
+    auto ld_el = [&](int i, int l) -> double {
+        if (i >= M || l >= M) return (i == l) ? 1.0 : 0.0;
+        return (i >= l) ? Y[i * ld + l] : Y[l * ld + i];
+    };
+    double a00 = ld_el(i0, l0), a01 = ld_el(i0, l1), a10 = ld_el(i1, l0), a11 = ld_el(i1, l1);
+    const int tri_bi = bi * (bi + 1) / 2, tri_bj = bj * (bj + 1) / 2;
+    int fail = 0;
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int jb = j / 2, tri_jb = jb * (jb + 1) / 2;
+        const bool odd = (j & 1);
+        // every lane "publishes" its two elements of column j (rows i0,i1 if it sits in block column jb; else, if it sits in
+        // block row jb, the two elements of ROW j, i.e. rows l0,l1 of column j by symmetry)
+        const bool incol = (bj == jb);
+        const double pub0 = incol ? (odd ? a01 : a00) : (odd ? a10 : a00);
+        const double pub1 = incol ? (odd ? a11 : a10) : (odd ? a11 : a01);
+        // pivot a(j,j): diagonal block lane (jb,jb)
+        const int dl = tri_jb + jb;
+        double piv = readlane_d(odd ? a11 : a00, dl);
+        if (!(piv > 1e-300)) { fail = 1; piv = 1e-300; }
+        const double p = fast_rcp(piv);
+        // c[r] for r in block row b: held by lane (b, jb) if b >= jb else lane (jb, b)
+        const int srcI = (bi >= jb) ? tri_bi + jb : tri_jb + bi;
+        const int srcL = (bj >= jb) ? tri_bj + jb : tri_jb + bj;
+        const double ci0 = bperm_d(pub0, srcI), ci1 = bperm_d(pub1, srcI), cl0 = bperm_d(pub0, srcL), cl1 = bperm_d(pub1, srcL);
+        auto upd = [&](double a, int i, int l, double ci, double cl) -> double {
+            if (i == j && l == j) return -p;
+            if (i == j) return cl * p;
+            if (l == j) return ci * p;
+            return fma(-ci * p, cl, a);
+        };
+        a00 = upd(a00, i0, l0, ci0, cl0); a01 = upd(a01, i0, l1, ci0, cl1);
+        a10 = upd(a10, i1, l0, ci1, cl0); a11 = upd(a11, i1, l1, ci1, cl1);
+    }
+    if (act) {   // Dinv = -swept, mirrored to the full matrix
+        if (i0 < M && l0 < M) { Dinv[i0 * ldi + l0] = -a00; Dinv[l0 * ldi + i0] = -a00; }
+        if (i0 < M && l1 < M && bi != bj) { Dinv[i0 * ldi + l1] = -a01; Dinv[l1 * ldi + i0] = -a01; }
+        if (i1 < M && l0 < M) { Dinv[i1 * ldi + l0] = -a10; Dinv[l0 * ldi + i1] = -a10; }
+        if (i1 < M && l1 < M) { Dinv[i1 * ldi + l1] = -a11; Dinv[l1 * ldi + i1] = -a11; }
+    }
+    wsync();
+    return fail;
+}
+
+// Lower Cholesky of the MxM SPD matrix Y (lower triangle read from LDS), then Linv = L^{-1} (full MxM written to LDS, upper
+// part zero).  Row i of the factor lives in lane i's registers; pivots, columns and the rows needed by the triangular
+// inverse are broadcast with v_readlane (SGPR operands of the FMAs), so the whole factorisation issues no LDS traffic and
+// no s_waitcnt between its 17 dependent steps.  Returns non-zero (wave-uniform) if a pivot was not positive (clamped).
+template <int M>
+__device__ __forceinline__ int chol_inv(const double *Y, int ld, double *Linv, int ldi, double * /*col*/, int lane) {
+    double row[M], rdiag[M];
     const bool act = lane < M;
 #pragma unroll
     for (int c = 0; c < M; c++) row[c] = (act && c <= lane) ? Y[lane * ld + c] : 0.0;
     int fail = 0;
 #pragma unroll
     for (int j = 0; j < M; j++) {
-        // pivot (held by lane j) -> broadcast
-        double d = __shfl(row[j], j);
+        double d = readlane_d(row[j], j);
         if (!(d > 1e-300)) { fail = 1; d = 1e-300; }
-        const double rs = 1.0 / sqrt(d);
-        if (act && lane >= j) row[j] = (lane == j) ? d * rs : row[j] * rs;
-        if (act) col[lane] = row[j];
-        wsync();
-        if (act) {
+        const double rs = fast_rsq(d);
+        rdiag[j] = rs;                                  // 1 / L[j][j]
+        row[j] = (lane == j) ? d * rs : row[j] * rs;    // lanes < j hold zeros there
 #pragma unroll
-            for (int l = j + 1; l < M; l++)
-                if (lane >= l) row[l] = fma(-row[j], col[l], row[l]);
+        for (int l = j + 1; l < M; l++) {
+            const double clj = readlane_d(row[j], l);   // L[l][j]
+            if (lane >= l) row[l] = fma(-row[j], clj, row[l]);
         }
-        wsync();
     }
-    // write L (lower) back, zero upper
-    if (act) {
-#pragma unroll
-        for (int c = 0; c < M; c++) Y[lane * ld + c] = (c <= lane) ? row[c] : 0.0;
-    }
-    wsync();
-    // inverse: lane c computes column c of X = L^{-1}
+    // inverse: lane c computes column c of X = L^{-1};  L[i][m] = row[m] of lane i
     double x[M];
 #pragma unroll
     for (int i = 0; i < M; i++) {
         double s = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-        for (int m = 0; m < i; m++) {
-            // l_im is wave-uniform (LDS broadcast); x[m] is zero for m < c
-            s = fma(-Y[i * ld + m], x[m], s);
-        }
-        const double xi = s / Y[i * ld + i];
-        x[i] = (act && i >= lane) ? xi : 0.0;
+        for (int m = 0; m < i; m++) s = fma(-readlane_d(row[m], i), x[m], s);   // x[m] = 0 for m < c
+        x[i] = (act && i >= lane) ? s * rdiag[i] : 0.0;
     }
     if (act) {
 #pragma unroll
@@ -212,7 +289,7 @@ __device__ __forceinline__ int chol_inv(double *Y, int ld, double *Linv, int ldi
 // Solve the small SPD system H z = f (NU x NU, H in LDS broadcast) redundantly per lane; f/z in registers.
 template <int NU>
 __device__ __forceinline__ void spd_solve_small(const double *H, int ld, double *f) {
-    double L[NU][NU];
+    double L[NU][NU], rd[NU];
 #pragma unroll
     for (int i = 0; i < NU; i++)
 #pragma unroll
@@ -220,14 +297,15 @@ __device__ __forceinline__ void spd_solve_small(const double *H, int ld, double 
             double s = H[i * ld + j];
 #pragma unroll
             for (int k = 0; k < j; k++) s = fma(-L[i][k], L[j][k], s);
-            L[i][j] = (i == j) ? sqrt(s) : s / L[j][j];
+            L[i][j] = (i == j) ? s * fast_rsq(s) : s * rd[j];
+            if (i == j) rd[j] = fast_rsq(s);
         }
 #pragma unroll
     for (int i = 0; i < NU; i++) {
         double s = f[i];
 #pragma unroll
         for (int k = 0; k < i; k++) s = fma(-L[i][k], f[k], s);
-        f[i] = s / L[i][i];
+        f[i] = s * rd[i];
     }
 #pragma unroll
     for (int i = NU - 1; i >= 0; i--) {

@@ -750,11 +750,11 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
         const double *e = eta + ((size_t)k * N + j) * NI;
         if (lane < NZ) sC[lane] = e[lane] + e[NZ + lane] + (lane < NX ? a.cst.Qregd[lane] : a.cst.Rregd[lane - NX]);
         wla::wsync();
-        wla::gemm<NU, NX, NX, true, false>(sB, NU, sS, NX, sX, NX, 1.0, 0.0, lane);   // x = B' S   (NU x NX)
-        wla::gemm<NX, NX, NX, true, false>(sA, NX, sS, NX, sYm, NX, 1.0, 0.0, lane);  // y = A' S   (NX x NX)
+        wla::gemm_blk<NU, NX, NX, true, false, 1, 2, false>(sB, NU, sS, NX, sX, NX, 1.0, lane);   // x = B' S   (NU x NX)
+        wla::gemm_blk<NX, NX, NX, true, false, 3, 2, false>(sA, NX, sS, NX, sYm, NX, 1.0, lane);  // y = A' S   (NX x NX)
         wla::wsync();
         wla::gemm<NU, NU, NX, false, false>(sX, NX, sB, NU, sH, NU, 1.0, 0.0, lane);  // H = x B
-        wla::gemm<NU, NX, NX, false, false>(sX, NX, sA, NX, sF, NX, 1.0, 0.0, lane);  // F = x A
+        wla::gemm_blk<NU, NX, NX, false, false, 1, 2, false>(sX, NX, sA, NX, sF, NX, 1.0, lane);  // F = x A
         wla::wsync();
         if (lane < NU) sH[lane * NU + lane] += sC[NX + lane];
         wla::wsync();
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
             sAcl[o] = s;
         }
         wla::wsync();
-        wla::gemm<NX, NX, NX, false, false>(sYm, NX, sAcl, NX, sSn, NX, 1.0, 0.0, lane);  // y (A + B K)
+        wla::gemm_blk<NX, NX, NX, false, false, 3, 2, false>(sYm, NX, sAcl, NX, sSn, NX, 1.0, lane);  // y (A + B K)
         wla::wsync();
 #pragma unroll
         for (int o = lane; o < NX * NX; o += 64) {
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
 #pragma unroll
         for (int o = lane; o < NX * NU; o += 64) { sB[o] = Bk[o]; sK[o] = Kg[o]; }
         wla::wsync();
-        wla::gemm<NU, NW, NX, false, false>(sK, NX, Pc, NW, sPu, NW, 1.0, 0.0, lane);  // Phi_u = K Phi_x
+        wla::gemm_blk<NU, NW, NX, false, false, 1, 2, false>(sK, NX, Pc, NW, sPu, NW, 1.0, lane);  // Phi_u = K Phi_x
 #pragma unroll
         for (int o = lane; o < NX * NX; o += 64) {
             const int i = o / NX, jj = o % NX;
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
             double *bo = beta + ((size_t)k * N + j) * NI;
             bo[lane] = s; bo[NZ + lane] = s;
         }
-        wla::gemm<NX, NW, NX, false, false>(sAcl, NX, Pc, NW, Pn, NW, 1.0, 0.0, lane);
+        wla::gemm_blk<NX, NW, NX, false, false, 3, 2, false>(sAcl, NX, Pc, NW, Pn, NW, 1.0, lane);
         wla::wsync();
         double *t = Pc; Pc = Pn; Pn = t;
     }

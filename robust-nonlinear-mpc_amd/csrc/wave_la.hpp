@@ -103,6 +103,50 @@ __device__ __forceinline__ void gemm_nt_blk(const double *A, int lda, const doub
     }
 }
 
+
+// General register-blocked product C(MxN) = alpha * op(A) op(B) [+ C], RBxCB outputs per lane, as many passes as needed.
+template <int M, int N, int K, bool TA, bool TB, int RB, int CB, bool ACC>
+__device__ __forceinline__ void gemm_blk(const double *A, int lda, const double *B, int ldb, double *C, int ldc, double alpha, int lane) {
+    constexpr int TR = (M + RB - 1) / RB, TC = (N + CB - 1) / CB, NTASK = TR * TC;
+#pragma unroll
+    for (int t0 = 0; t0 < NTASK; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < NTASK) {
+            const int tr = t / TC, tc = t % TC;
+            int ri[RB], cj[CB];
+#pragma unroll
+            for (int r = 0; r < RB; r++) ri[r] = min(tr * RB + r, M - 1);
+#pragma unroll
+            for (int q = 0; q < CB; q++) cj[q] = min(tc * CB + q, N - 1);
+            double acc[RB][CB];
+#pragma unroll
+            for (int r = 0; r < RB; r++)
+#pragma unroll
+                for (int q = 0; q < CB; q++) acc[r][q] = 0.0;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                double a[RB], b[CB];
+#pragma unroll
+                for (int r = 0; r < RB; r++) a[r] = TA ? A[k * lda + ri[r]] : A[ri[r] * lda + k];
+#pragma unroll
+                for (int q = 0; q < CB; q++) b[q] = TB ? B[cj[q] * ldb + k] : B[k * ldb + cj[q]];
+#pragma unroll
+                for (int r = 0; r < RB; r++)
+#pragma unroll
+                    for (int q = 0; q < CB; q++) acc[r][q] = fma(a[r], b[q], acc[r][q]);
+            }
+#pragma unroll
+            for (int r = 0; r < RB; r++)
+#pragma unroll
+                for (int q = 0; q < CB; q++)
+                    if (tr * RB + r < M && tc * CB + q < N) {
+                        double *c = C + (tr * RB + r) * ldc + tc * CB + q;
+                        *c = ACC ? fma(alpha, acc[r][q], *c) : alpha * acc[r][q];
+                    }
+        }
+    }
+}
+
 // Lower triangle (i >= j) of  Y = M1 A' + B diag(piu) B' - T M1' + diag(d) ,  all NX x NX (B: NX x NU), 2x2 blocks, one pass.
 // useT = false drops the T term.  Only the lower triangle of Y is written (the Cholesky reads nothing else).
 template <int NX, int NU>

@@ -95,6 +95,7 @@ def main():
     collect()   # warm the gather path too (first-use kernel loads are not part of the step)
     barrier()
     t_qp = t_sw = t_tot = 0.0
+    f.kernel_timing()   # reset the per-kernel accumulators
     host_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -108,6 +109,7 @@ def main():
     collect()
     barrier()
     dt = time.perf_counter() - t0
+    fwd_total_ms, fwd_launches = f.kernel_timing()
     if world > 1:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -127,15 +129,33 @@ def main():
                    "qp2_cold_fallback_frac": float(np.mean(its > 0)), "tightened_frac": float(np.mean(f.get("backoff_x", (N + 1, m.nx)).max(axis=(1, 2)) > 0))},
     }
     if rank == 0:
-        avg_qp_ms = t_qp / launches
-        alg_bytes = QP_BYTES[args.model] * B
-        achieved = alg_bytes / (avg_qp_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_qp", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                           "traffic": None, "avg_launch_ms": avg_qp_ms, "algorithmic_bytes_per_launch": alg_bytes,
+        kk = f.get("kkt", (8,))
+        # dominant kernel: k_ne_fwd (block-tridiagonal forward sweep; re-factorises in half of its launches).  Algorithmic bytes
+        # of one launch = for every instance that does work: A_k,B_k of all stages in, rhs slices (Pi, v) in, u out.
+        nz = m.nx + m.nu
+        per_inst = 8 * (N * m.nx * nz + 2 * f.n + N * m.nx)
+        fwd_ms = fwd_total_ms / max(1, fwd_launches)
+        inst_launches_last_qp = float(kk[:, 7].sum())           # instance-launches of the last QP solve (device counters)
+        # all QP solves of the timed region: scale the last solve's instance-launch count by the measured launch counts
+        alg_bytes_launch = per_inst * inst_launches_last_qp / max(1.0, kk[:, 7].max())
+        achieved = alg_bytes_launch / (fwd_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("k_ne_fwd_bytes_per_launch")
+        qp_ms = t_qp / launches
+        # fp64 work of one QP solve: 28.6 kflop per factorised stage, 2 kflop per solve-only stage sweep
+        flop_last = float((kk[:, 6] * N * 28.6e3 + (kk[:, 7] - kk[:, 6]) * N * 2.0e3 + kk[:, 7] * N * 2.0e3).sum())
+        out["roofline"] = {"bound": "hbm", "kernel": "k_ne_fwd", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                           "traffic": traffic, "avg_launch_ms": fwd_ms, "launches": fwd_launches, "algorithmic_bytes_per_launch": alg_bytes_launch,
+                           "qp_solve": {"avg_ms": qp_ms, "algorithmic_bytes": QP_BYTES[args.model] * B,
+                                        "achieved_GBps": QP_BYTES[args.model] * B / (qp_ms * 1e-3) / 1e9},
+                           "fp64": {"achieved_TFLOPs_last_qp": flop_last / (qp_ms * 1e-3) / 1e12 if qp_ms > 0 else None, "peak_TFLOPs": 78.6,
+                                    "note": "vector fp64 peak from BASELINE.md (AMD public figure); the guide lists no fp64 peak"},
                            "sweep_avg_launch_ms": t_sw / args.steps, "solve_call_gpu_ms": t_tot / args.steps,
                            "host_ms_per_step": [round(x, 2) for x in host_ms]}
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(batch, 64)
+            out["cpu_baseline"] = cpu_baseline(batch, 1024, budget_s=20.0)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -117,6 +117,9 @@ int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta_f, double 
 /* elapsed GPU time (ms) of the kernels launched by the last slsqp_solve / slsqp_qp_solve / slsqp_sweep call,
    measured with HIP events on the handle's stream: [0] total, [1] QP kernel(s), [2] sweep kernel, [3] other */
 int slsqp_last_timing(slsqp_handle *h, double *ms4);
+/* accumulated since the last call: [0] total ms of k_ne_fwd launches (HIP events around each launch, handle's stream),
+   [1] number of launches; resets the accumulators */
+int slsqp_kernel_timing(slsqp_handle *h, double *out3);
 void *slsqp_stream(slsqp_handle *h); /* hipStream_t, for callers that share device buffers */
 
 #ifdef __cplusplus

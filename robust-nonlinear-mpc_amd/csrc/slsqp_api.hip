@@ -49,7 +49,9 @@ struct slsqp_handle {
     size_t stage_bytes;
     bool have_costs, have_cons, have_dyn;
     hipEvent_t ev[8];
-    double t_total, t_qp, t_sweep;
+    std::vector<hipEvent_t> kev;   // event pairs around every k_ne_fwd launch of the last QP solve
+    int n_kev;
+    double t_total, t_qp, t_sweep, t_fwd; int n_fwd; double fwd_inst;   // fwd_inst: sum over launches of instances that did work
     std::map<std::string, std::pair<void *, size_t>> named;  // name -> (device ptr, bytes per instance)
 };
 
@@ -98,7 +100,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->x0val, B * nx); rc |= dalloc(&h->gf_raw, (size_t)nif); rc |= dalloc(&h->cst, (size_t)(3 * nx + 2 * nu) * 2);
     rc |= dalloc(&h->ubg, B * h->mb); rc |= dalloc(&h->lbg, B * h->mb);
     rc |= dalloc(&h->primal, B * h->n); rc |= dalloc(&h->dual, B * h->mb); rc |= dalloc(&h->cost, B); rc |= dalloc(&h->pin_dual, B * nx);
-    rc |= dalloc(&h->kkt, B * 8); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx); rc |= dalloc(&h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(&h->qpstate, B * 16);
+    rc |= dalloc(&h->kkt, B * 8); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx); rc |= dalloc(&h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(&h->qpstate, B * 18);
     rc |= dalloc(&h->eta, B * N * N * ni); rc |= dalloc(&h->eta_f, B * (N + 1) * nif); rc |= dalloc(&h->beta, B * N * N * ni);
     rc |= dalloc(&h->beta_f, B * (N + 1) * nif); rc |= dalloc(&h->backoff, B * N * ni); rc |= dalloc(&h->backoff_f, B * nif);
     rc |= dalloc(&h->backoff_x, B * (N + 1) * nx); rc |= dalloc(&h->backoff_u, B * N * nu); rc |= dalloc(&h->K, B * N * (N + 1) * nu * nx);
@@ -107,6 +109,8 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->mapA, (size_t)N * nx * nx); rc |= dalloc(&h->mapB, (size_t)N * nx * nu);
     if (rc) { delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
+    h->kev.resize(2 * 256); for (auto &e : h->kev) hipEventCreate(&e);
+    h->n_kev = 0; h->t_fwd = 0; h->n_fwd = 0; h->fwd_inst = 0;
     // CSC offsets of the reference's frozen pattern (qp_jit.py:101-123,178-186; columns sorted by row)
     {
         std::vector<int> mA((size_t)N * nx * nx), mB((size_t)N * nx * nu);
@@ -153,6 +157,7 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
                     h->counter, h->mapA, h->mapB};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : h->ev) hipEventDestroy(e);
+    for (auto &e : h->kev) hipEventDestroy(e);
     hipStreamDestroy(h->st);
     delete h;
 }
@@ -289,7 +294,10 @@ static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter) {
     while (tick < max_ticks && active > 0) {
         const int burst = tick < 12 ? 12 : 3;
         for (int i = 0; i < burst; i++, tick++) {
+            const bool timed = h->n_kev + 2 <= (int)h->kev.size();
+            if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
             hipLaunchKernelGGL((k_ne_fwd<NX, NU>), grid, blk, lds, h->st, a);
+            if (timed) { hipEventRecord(h->kev[h->n_kev + 1], h->st); h->n_kev += 2; }
             hipLaunchKernelGGL((k_ne_bwd<NX, NU>), grid, blk, lds, h->st, a);
             hipLaunchKernelGGL((k_phase<NX, NU>), grid, blk, 0, h->st, a, 0);
         }
@@ -297,6 +305,8 @@ static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter) {
         HIPCHK(hipStreamSynchronize(h->st));
     }
     HIPCHK(hipGetLastError());
+    for (int i = 0; i + 1 < h->n_kev; i += 2) { float ms = 0; hipEventElapsedTime(&ms, h->kev[i], h->kev[i + 1]); h->t_fwd += ms; h->n_fwd++; }
+    h->n_kev = 0;
     return 0;
 }
 
@@ -392,6 +402,11 @@ extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const sls
 
 extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms4) {
     ms4[0] = h->t_total; ms4[1] = h->t_qp; ms4[2] = h->t_sweep; ms4[3] = h->t_total - h->t_qp - h->t_sweep;
+    return 0;
+}
+extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out3) {
+    out3[0] = h->t_fwd; out3[1] = (double)h->n_fwd; out3[2] = 0.0;
+    h->t_fwd = 0; h->n_fwd = 0;
     return 0;
 }
 

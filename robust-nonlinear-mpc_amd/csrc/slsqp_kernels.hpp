@@ -61,7 +61,7 @@ struct QpArgs {
     double *cost;             // (B)
     double *pin_dual;         // (B,NX) multipliers of the x0-pin rows (may be NULL)
     double *kkt;              // (B,8) [0..3] accepted solution: stationarity, box violation, multiplier-sign violation, mu;
-                              //       [4..7] last polish attempt: stationarity, box, sign, factorisation-failed flag
+                              //       [4],[5] last polish attempt: stationarity, box; [6],[7] factor sweeps / solves used
     int *status, *iters;      // (B)
     int max_iter;
     double eps;
@@ -282,8 +282,8 @@ __device__ __forceinline__ Elem elem_of(int e, int n, int N, const double *ub, c
 // finished instances exit at once.  Splitting the former single kernel removed 340 VGPR + 382 SGPR spills.
 // ------------------------------------------------------------------------------------------------
 enum { P_INIT = 0, P_PRED = 1, P_CORR = 2, P_POL0 = 3, P_POL1 = 4, P_POL2 = 5, P_DONE = 6 };
-struct QpState {   // per instance, 16 doubles
-    double phase, it, status, mu, smu, qscale, mtot, pol_round, pol_fail, warm, kst, kbox, ksign, pst, pbox, psign;
+struct QpState {   // per instance, 18 doubles
+    double phase, it, status, mu, smu, qscale, mtot, pol_round, pol_fail, warm, kst, kbox, ksign, pst, pbox, psign, ticks, fticks;
 };
 
 template <int NX, int NU>
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
     const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
     const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane,
                                      (long long *)(a.kkt + (size_t)b * 8));
-    if (lane == 0 && factor && phase == P_POL0) st->pol_fail = f;
+    if (lane == 0) { st->ticks += 1.0; if (factor) { st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
 }
 
 template <int NX, int NU>
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
         if (lane == 0) {
             QpState s0;
             s0.phase = (status == ST_INIT) ? (warm ? P_POL0 : P_INIT) : P_DONE; s0.it = 0; s0.status = status; s0.mu = 0; s0.smu = 0; s0.qscale = qscale;
-            s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1;
+            s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1; s0.ticks = 0; s0.fticks = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
             if (status == ST_INIT) atomicAdd(a.n_active, 1);
@@ -615,12 +615,12 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
             a.iters[b] = it;
 #ifndef NE_STAMP
             double *kk = a.kkt + (size_t)b * 8;
-            kk[0] = s.kst; kk[1] = s.kbox; kk[2] = s.ksign; kk[3] = s.mu; kk[4] = s.pst; kk[5] = s.pbox; kk[6] = s.psign; kk[7] = s.pol_fail;
+            kk[0] = s.kst; kk[1] = s.kbox; kk[2] = s.ksign; kk[3] = s.mu; kk[4] = s.pst; kk[5] = s.pbox; kk[6] = stp->fticks; kk[7] = stp->ticks;   // [6],[7]: factor sweeps / block-tridiagonal solves this instance used
 #endif
             atomicAdd(a.n_active, -1);
         }
     }
-    if (lane == 0) { s.phase = phase; s.it = it; s.status = status; *stp = s; }
+    if (lane == 0) { s.phase = phase; s.it = it; s.status = status; s.ticks = stp->ticks; s.fticks = stp->fticks; *stp = s; }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -109,6 +109,12 @@ class BatchedFastSLS:
         self.lib.slsqp_last_timing(self.h, _ptr(t))
         return dict(total=t[0], qp=t[1], sweep=t[2], other=t[3])
 
+    def kernel_timing(self):
+        """(total ms, launches) of the dominant kernel k_ne_fwd since the last call (HIP events on the handle's stream)."""
+        t = np.zeros(3)
+        self.lib.slsqp_kernel_timing(self.h, _ptr(t))
+        return t[0], int(t[1])
+
     def solve(self, x0, fetch=True):
         """x0: (B,nx) = x_nom0 - x_meas (the argument SCP_SLS.socp_step passes, SCP_SLS_jit.py:408-410)."""
         x0 = _c(x0)

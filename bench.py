@@ -73,7 +73,7 @@ def main():
     m, N = batch["model"], batch["N"]
     f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=B, device=local_rank)
     f.set_rti_steps(m.fast_sls_rti_steps if args.model == "rocket" else 1)
-    f.opts.warm_rounds = int(os.environ.get('QP_WARM_ROUNDS', '3'))
+    f.opts.warm_rounds = int(os.environ.get('QP_WARM_ROUNDS', '4'))
     f.opts.warm_start = 0   # QP#1 of every step is solved cold (fresh Monte-Carlo instances); QP#2 warm-starts from QP#1
     dev = DeviceBatch(f, batch)
 

@@ -63,7 +63,7 @@ typedef struct {
     int want_K;          /* also keep K (N,N+1,nu,nx) for slsqp_get */
     int warm_start;      /* 1 (default): the first QP of a call first tries an active-set polish from the instance's previous
                             certified solution (KKT-verified, falls back to the interior point); later QPs of a call always do */
-    int warm_rounds;     /* active-set correction rounds a warm attempt may use before falling back (default 3) */
+    int warm_rounds;     /* active-set correction rounds a warm attempt may use before falling back (default 4) */
 } slsqp_opts;
 
 void slsqp_default_opts(slsqp_opts *o);

@@ -29,7 +29,7 @@ extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
     o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-8; o->conv_tol = 1e-3;
-    o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 3;
+    o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 4;
 }
 
 struct slsqp_handle {
@@ -289,7 +289,7 @@ static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter) {
     hipLaunchKernelGGL((k_phase<NX, NU>), grid, blk, 0, h->st, a, 1);
     // every instance needs 1 (start) + 2 per interior-point iteration + 3 per polish round ticks; poll the number of
     // unfinished instances every few ticks instead of running the worst case
-    const int max_ticks = 1 + 2 * max_iter + 3 * 7 + 2;
+    const int max_ticks = 1 + 2 * max_iter + 3 + 2 * 10 + 8 + 2;
     int tick = 0, active = 1;
     while (tick < max_ticks && active > 0) {
         const int burst = tick < 12 ? 12 : 3;

@@ -116,15 +116,16 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
     auto prefetch = [&](int k) {
         const double *Ak = g.A + (size_t)k * MM, *Bk = g.Bm + (size_t)k * NX * NU, *Lg = g.Linv + (size_t)k * MM;
 #pragma unroll
-        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; rA[r] = (o < MM) ? Ak[o] : 0.0; }
+        for (int r = 0; r < RA; r++) rA[r] = Ak[min(r * 64 + lane, MM - 1)];
 #pragma unroll
-        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; rB[r] = (o < NX * NU) ? Bk[o] : 0.0; }
+        for (int r = 0; r < RB; r++) rB[r] = Bk[min(r * 64 + lane, NX * NU - 1)];
         if (!factor) {
 #pragma unroll
-            for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; rL[r] = (o < MM) ? Lg[o] : 0.0; }
+            for (int r = 0; r < RA; r++) rL[r] = Lg[min(r * 64 + lane, MM - 1)];
         }
-        if (lane < NZ + NX) { rPi = g.PI[k * NZ + lane]; rV = g.V[k * NZ + lane]; }
-        if (lane < NX && eflag != 0.0) rE = 0.5 * (g.ub[k * SR + lane] + g.lb[k * SR + lane]);
+        const int ls = min(lane, NZ + NX - 1), lx = min(lane, NX - 1);
+        rPi = g.PI[k * NZ + ls]; rV = g.V[k * NZ + ls];
+        if (eflag != 0.0) rE = 0.5 * (g.ub[k * SR + lx] + g.lb[k * SR + lx]);
     };
     prefetch(0);
     for (int k = 0; k < g.N; k++) {
@@ -209,10 +210,11 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
     auto prefetch = [&](int k) {
         const double *Ak = g.A + (size_t)k * MM, *Bk = g.Bm + (size_t)k * NX * NU, *Lg = g.Linv + (size_t)k * MM;
 #pragma unroll
-        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; rA[r] = (o < MM) ? Ak[o] : 0.0; rL[r] = (o < MM) ? Lg[o] : 0.0; }
+        for (int r = 0; r < RA; r++) { const int o = min(r * 64 + lane, MM - 1); rA[r] = Ak[o]; rL[r] = Lg[o]; }
 #pragma unroll
-        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; rB[r] = (o < NX * NU) ? Bk[o] : 0.0; }
-        if (lane < NX) { rPi = g.PI[(k + 1) * NZ + lane]; rW = g.W[k * NX + lane]; }
+        for (int r = 0; r < RB; r++) rB[r] = Bk[min(r * 64 + lane, NX * NU - 1)];
+        const int lx = min(lane, NX - 1);
+        rPi = g.PI[(k + 1) * NZ + lx]; rW = g.W[k * NX + lx];
     };
     prefetch(g.N - 1);
     for (int k = g.N - 1; k >= 0; k--) {
@@ -487,7 +489,41 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
         }
         for (int o = lane; o < N * NX; o += 64) NUP[o] = (firstp ? 0.0 : NUP[o]) + W[o];
         wla::wsync_mem();
-        if (phase != P_POL2) {
+        const double max_rounds = (s.warm != 0.0) ? (double)a.warm_rounds : 8.0;
+        bool again = false;
+        if (phase == P_POL0 && s.pol_fail == 0.0 && s.pol_round < max_rounds) {
+            // cheap look at the un-refined solve: if the active set is visibly wrong (coarse tolerance) correct it now and
+            // factorise again, without spending the two refinement solves on a set that is about to change
+            const double ctol = 1e-6 * qscale;
+            int changed = 0;
+            for (int e = lane; e < n; e += 64) {
+                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                const double zn = CU[e], gr = el.pd * zn + el.q + CL[e], ac = ACT[e];
+                if ((ac > 0.0 && gr > ctol) || (ac < 0.0 && -gr > ctol)) changed = 1;
+                if (ac == 0.0 && ((el.fu && zn > el.hi + ctol) || (el.fl && zn < el.lo - ctol))) changed = 1;
+            }
+            again = wla::wave_or(changed) != 0;
+            if (again) {
+                s.pol_round += 1.0;
+                for (int e = lane; e < n; e += 64) {
+                    const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                    const double zn = CU[e], gr = el.pd * zn + el.q + CL[e];
+                    double ac = ACT[e];
+                    if (ac > 0.0 && gr > ctol) ac = 0.0;
+                    if (ac < 0.0 && -gr > ctol) ac = 0.0;
+                    if (ac == 0.0) {
+                        if (el.fu && zn > el.hi + ctol) ac = 1.0;
+                        else if (el.fl && zn < el.lo - ctol) ac = -1.0;
+                    }
+                    const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zn);
+                    const double pi = (el.fr && ac == 0.0) ? 1.0 / el.pd : 0.0;
+                    ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
+                }
+            }
+        }
+        if (again) {
+            phase = P_POL0;
+        } else if (phase != P_POL2) {
             for (int e = lane; e < n; e += 64) {
                 const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
                 const double pi = PI[e], zn = CU[e];
@@ -512,7 +548,7 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
             if (!pf && vst < ptol && vbox < ptol && vsign < ptol) {
                 polished = true; status = 0; s.kst = vst; s.kbox = vbox; s.ksign = vsign;
                 phase = P_DONE;
-            } else if (!pf && vst < ptol && s.pol_round < (s.warm != 0.0 ? (double)a.warm_rounds : 6.0)) {
+            } else if (!pf && vst < ptol && s.pol_round < max_rounds) {
                 // primal-dual active-set correction: release constraints whose multiplier has the wrong sign,
                 // add violated bounds, factorise again
                 s.pol_round += 1.0;

@@ -236,6 +236,8 @@ __device__ __forceinline__ double bperm_d(double v, int src_lane) {
 
 template <int M>
 __device__ __forceinline__ int spd_inv_gj(const double *Y, int ld, double *Dinv, int ldi, double * /*col*/, int lane) {
+    // Block (2x2 pivots) symmetric Gauss-Jordan sweep: T = ceil(M/2) rounds instead of M; branch-free.
+    //   P = A_JJ ;  A_IL -= A_IJ P^-1 A_JL (I,L not J) ;  A_IJ <- A_IJ P^-1 ;  A_JL <- P^-1 A_JL ;  A_JJ <- -P^-1 ;  result = -A^-1
     constexpr int T = (M + 1) / 2, NT = T * (T + 1) / 2;
     static_assert(NT <= 64, "one wave");
     int bi = 0, rem = min(lane, NT - 1);
@@ -245,39 +247,46 @@ __device__ __forceinline__ int spd_inv_gj(const double *Y, int ld, double *Dinv,
     const int i0 = 2 * bi, i1 = i0 + 1, l0 = 2 * bj, l1 = l0 + 1;
     // padded (2T x 2T) matrix: identity in the padding row/col when M is odd
     auto ld_el = [&](int i, int l) -> double {
-        if (i >= M || l >= M) return (i == l) ? 1.0 : 0.0;
-        return (i >= l) ? Y[i * ld + l] : Y[l * ld + i];
+        const bool pad = (i >= M) | (l >= M);
+        const int ii = min(i, M - 1), ll = min(l, M - 1);
+        const double v = (ii >= ll) ? Y[ii * ld + ll] : Y[ll * ld + ii];
+        return pad ? ((i == l) ? 1.0 : 0.0) : v;
     };
     double a00 = ld_el(i0, l0), a01 = ld_el(i0, l1), a10 = ld_el(i1, l0), a11 = ld_el(i1, l1);
     const int tri_bi = bi * (bi + 1) / 2, tri_bj = bj * (bj + 1) / 2;
     int fail = 0;
 #pragma unroll
-    for (int j = 0; j < M; j++) {
-        constexpr int dummy = 0; (void)dummy;
-        const int jb = j / 2, tri_jb = jb * (jb + 1) / 2;
-        const bool odd = (j & 1);
-        // every lane "publishes" its two elements of column j (rows i0,i1 if it sits in block column jb; else, if it sits in
-        // block row jb, the two elements of ROW j, i.e. rows l0,l1 of column j by symmetry)
-        const bool incol = (bj == jb);
-        const double pub0 = incol ? (odd ? a01 : a00) : (odd ? a10 : a00);
-        const double pub1 = incol ? (odd ? a11 : a10) : (odd ? a11 : a01);
-        // pivot a(j,j): diagonal block lane (jb,jb)
-        const int dl = tri_jb + jb;
-        double piv = readlane_d(odd ? a11 : a00, dl);
-        if (!(piv > 1e-300)) { fail = 1; piv = 1e-300; }
-        const double p = fast_rcp(piv);
-        // c[r] for r in block row b: held by lane (b, jb) if b >= jb else lane (jb, b)
-        const int srcI = (bi >= jb) ? tri_bi + jb : tri_jb + bi;
-        const int srcL = (bj >= jb) ? tri_bj + jb : tri_jb + bj;
-        const double ci0 = bperm_d(pub0, srcI), ci1 = bperm_d(pub1, srcI), cl0 = bperm_d(pub0, srcL), cl1 = bperm_d(pub1, srcL);
-        auto upd = [&](double a, int i, int l, double ci, double cl) -> double {
-            if (i == j && l == j) return -p;
-            if (i == j) return cl * p;
-            if (l == j) return ci * p;
-            return fma(-ci * p, cl, a);
-        };
-        a00 = upd(a00, i0, l0, ci0, cl0); a01 = upd(a01, i0, l1, ci0, cl1);
-        a10 = upd(a10, i1, l0, ci1, cl0); a11 = upd(a11, i1, l1, ci1, cl1);
+    for (int jb = 0; jb < T; jb++) {
+        const int tri_jb = jb * (jb + 1) / 2, dl = tri_jb + jb;
+        // pivot block (uniform): P = [[pa, pb],[pb, pc]] from the diagonal lane; P^-1 by two scalar eliminations (as stable as 1x1 pivots)
+        const double pa = readlane_d(a00, dl), pb = readlane_d(a10, dl), pc = readlane_d(a11, dl);
+        double d1 = pa;
+        if (!(d1 > 1e-300)) { fail = 1; d1 = 1e-300; }
+        const double r1 = fast_rcp(d1), bp = pb * r1;
+        double d2 = fma(-pb, bp, pc);
+        if (!(d2 > 1e-300)) { fail = 1; d2 = 1e-300; }
+        const double r2 = fast_rcp(d2);
+        const double q11 = r2, q01 = -bp * r2, q00 = fma(bp * bp, r2, r1);      // P^-1 = [[q00, q01],[q01, q11]]
+        // C_I = A_{I,J} (2x2): lane (bi, jb) if bi > jb, else lane (jb, bi) transposed;  C_L = A_{L,J} likewise
+        const int srcI = (bi >= jb) ? tri_bi + jb : tri_jb + bi, srcL = (bj >= jb) ? tri_bj + jb : tri_jb + bj;
+        const double f00 = bperm_d(a00, srcI), f01 = bperm_d(a01, srcI), f10 = bperm_d(a10, srcI), f11 = bperm_d(a11, srcI);
+        const double g00 = bperm_d(a00, srcL), g01 = bperm_d(a01, srcL), g10 = bperm_d(a10, srcL), g11 = bperm_d(a11, srcL);
+        const bool tI = bi < jb, tL = bj < jb;
+        const double ci00 = f00, ci01 = tI ? f10 : f01, ci10 = tI ? f01 : f10, ci11 = f11;
+        const double cl00 = g00, cl01 = tL ? g10 : g01, cl10 = tL ? g01 : g10, cl11 = g11;
+        // general update: B -= (C_I P^-1) C_L'
+        const double t00 = fma(ci00, q00, ci01 * q01), t01 = fma(ci00, q01, ci01 * q11);
+        const double t10 = fma(ci10, q00, ci11 * q01), t11 = fma(ci10, q01, ci11 * q11);
+        const double n00 = fma(-t00, cl00, fma(-t01, cl01, a00)), n01 = fma(-t00, cl10, fma(-t01, cl11, a01));
+        const double n10 = fma(-t10, cl00, fma(-t11, cl01, a10)), n11 = fma(-t10, cl10, fma(-t11, cl11, a11));
+        // block column jb (rows below the pivot): B <- B P^-1 ; block row jb (cols left of the pivot): B <- P^-1 B
+        const double c00 = fma(a00, q00, a01 * q01), c01 = fma(a00, q01, a01 * q11), c10 = fma(a10, q00, a11 * q01), c11 = fma(a10, q01, a11 * q11);
+        const double w00 = fma(q00, a00, q01 * a10), w01 = fma(q00, a01, q01 * a11), w10 = fma(q01, a00, q11 * a10), w11 = fma(q01, a01, q11 * a11);
+        const bool isD = (bi == jb) & (bj == jb), inC = (bj == jb) & !isD, inR = (bi == jb) & !isD;
+        a00 = isD ? -q00 : (inC ? c00 : (inR ? w00 : n00));
+        a01 = isD ? -q01 : (inC ? c01 : (inR ? w01 : n01));
+        a10 = isD ? -q01 : (inC ? c10 : (inR ? w10 : n10));
+        a11 = isD ? -q11 : (inC ? c11 : (inR ? w11 : n11));
     }
     if (act) {   // Dinv = -swept, mirrored to the full matrix
         if (i0 < M && l0 < M) { Dinv[i0 * ldi + l0] = -a00; Dinv[l0 * ldi + i0] = -a00; }

@@ -95,10 +95,20 @@ int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *op
 /* Fetch a result array by name into `out` (host or device).  Names and shapes (B leading):
    primal_vec (n) dual_vec (m-nx) cost_nominal (1) status[int32] (1) qp_iters[int32] (1) iteration_number[int32] (1)
    beta (N,N,ni) beta_f (N+1,ni_f) backoff (N,ni) backoff_f (ni_f) backoff_x (N+1,nx) backoff_u (N,nu)
-   eta (N,N,ni) eta_f (N+1,ni_f) K (N,N+1,nu,nx) ubg (m-nx) lbg (m-nx) kkt (8) pin_dual (nx) success[int32] (1) */
+   eta (N,N,ni) eta_f (N+1,ni_f) K (N,N+1,nu,nx) ubg (m-nx) lbg (m-nx) kkt (8) pin_dual (nx) success[int32] (1)
+   and the current problem data: A (N,nx,nx) Bm (N,nx,nu) c (N,nx) g (N,ni) gN (ni_f) q (n) */
 int slsqp_get(slsqp_handle *h, const char *name, void *out, int loc);
 int slsqp_reset(slsqp_handle *h);
 int slsqp_sync(slsqp_handle *h);
+
+/* ---- the step in front of the path: batched linearisation (SCP_SLS.update_jacobian, solver/SCP_SLS_jit.py:251-366) ---------
+   model_id: 0 pendulum, 1 quadrotor, 2 rocket (dyn/*.py ODEs, RK4 h=0.05, dyn/model.py:15-34); g_raw (ni): the plant's stage bound g.
+   slsqp_linearize: X (B,N+1,nx), U (B,N,nu) nominal trajectories (stage-major) -> A,B (forward-mode AD through RK4),
+   c_k = f(x_k,u_k) - x_{k+1}, g_k = g - G[x_k;u_k], g_N = gf - Gf x_N, q = 2 H y_nom, then the un-tightened bounds; E is untouched
+   (set it once with slsqp_update_dynamics or slsqp_set_E). Equivalent to update_dynamics + update_linear_cost. */
+int slsqp_set_model(slsqp_handle *h, int model_id, const double *g_raw);
+int slsqp_set_E(slsqp_handle *h, const double *E, int loc);   /* E (N+1,nx,nw) */
+int slsqp_linearize(slsqp_handle *h, const double *X, const double *U, int loc);
 
 /* ---- QP-level boundary: mirrors the three calls of the reference's generated module ----------------------- */
 /* P_x (B,nnzP): CSC data of triu(2P) (diagonal => nnzP = n);  A_x (B,nnzA): CSC data of the (m x n) constraint

@@ -1,0 +1,178 @@
+// dynamics.hpp -- the three plants of the reference as templated C++ (host + device), RK4 discretisation and
+// forward-mode AD, used by the batched linearisation kernel (the step that feeds the fast-SLS path).
+//
+// Restated from (citations relative to antoineleeman/robust-nonlinear-mpc):
+//   Pendulum.ode   dyn/pendulum.py:26-44      (cart-pole, m1=1, m2=0.1, l=0.5, g=9.81)
+//   Quadrotor.ode  dyn/quadrotor.py:108-174   (m=1, g=9.81, l=0.15, J=diag(0.02,0.02,0.04), kM=0.01)
+//   Rocket.ode     dyn/rocket.py:165-254      (parameters :24-38; gimbal linkage `compute_gimbal_angle` :246-254)
+//   Model.ddyn     dyn/model.py:15-34         (RK4, h = 0.05 always: SURVEY quirk q8)
+// Pinned by tests/golden/dyn_*.npz (values of ode/ddyn produced by the reference's own source; Jacobians by central
+// differences of the reference's ddyn).
+#pragma once
+#include <math.h>
+#ifndef __HIPCC__
+#ifndef __host__
+#define __host__
+#endif
+#ifndef __device__
+#define __device__
+#endif
+#endif
+#define DYN_HD __host__ __device__ inline
+
+namespace dyn {
+
+// ---- scalar types: double, or value + one directional derivative -------------------------------------------------
+struct Dual {
+    double v, d;
+    DYN_HD Dual() : v(0.0), d(0.0) {}
+    DYN_HD Dual(double a) : v(a), d(0.0) {}
+    DYN_HD Dual(double a, double b) : v(a), d(b) {}
+};
+DYN_HD Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d + b.d); }
+DYN_HD Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d - b.d); }
+DYN_HD Dual operator-(Dual a) { return Dual(-a.v, -a.d); }
+DYN_HD Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
+DYN_HD Dual operator/(Dual a, Dual b) { const double q = a.v / b.v; return Dual(q, (a.d - q * b.d) / b.v); }
+DYN_HD Dual msin(Dual a) { return Dual(sin(a.v), cos(a.v) * a.d); }
+DYN_HD Dual mcos(Dual a) { return Dual(cos(a.v), -sin(a.v) * a.d); }
+DYN_HD Dual msqrt(Dual a) { const double s = sqrt(a.v); return Dual(s, 0.5 * a.d / s); }
+DYN_HD Dual matan(Dual a) { return Dual(atan(a.v), a.d / (1.0 + a.v * a.v)); }
+DYN_HD double msin(double a) { return sin(a); }
+DYN_HD double mcos(double a) { return cos(a); }
+DYN_HD double msqrt(double a) { return sqrt(a); }
+DYN_HD double matan(double a) { return atan(a); }
+DYN_HD double val(double a) { return a; }
+DYN_HD double val(Dual a) { return a.v; }
+
+constexpr int MODEL_PENDULUM = 0, MODEL_QUADROTOR = 1, MODEL_ROCKET = 2;
+constexpr double RK4_H = 0.05;
+
+// ---- ODEs ---------------------------------------------------------------------------------------------------------
+template <typename T>
+DYN_HD void ode_pendulum(const T *X, const T *U, T *dX) {
+    const T xd = X[1], th = X[2], thd = X[3], u = U[0];
+    const double m1 = 1.0, m2 = 0.1, l = 0.5, g = 9.81;
+    const T s = msin(th), c = mcos(th);
+    const T den = T(m1) + T(m2) * (T(1.0) - c * c);
+    const T xdd = (u + T(m2 * l) * thd * thd * s - T(m2 * g) * s * c) / den;
+    const T thdd = (-u * c - T(m2 * l) * thd * thd * s * c + T((m1 + m2) * g) * s) / (T(l) * den);
+    dX[0] = xd; dX[1] = xdd; dX[2] = thd; dX[3] = thdd;
+}
+
+// rotation matrix body->world of q = [qw,qx,qy,qz] applied to a body vector (quadrotor.py:124-138 / rocket.py:196-210)
+template <typename T>
+DYN_HD void rot_apply(T qw, T qx, T qy, T qz, T bx, T by, T bz, T &wx, T &wy, T &wz) {
+    const T two(2.0), one(1.0);
+    const T r00 = one - two * qy * qy - two * qz * qz, r01 = two * qx * qy - two * qz * qw, r02 = two * qx * qz + two * qy * qw;
+    const T r10 = two * qx * qy + two * qz * qw, r11 = one - two * qx * qx - two * qz * qz, r12 = two * qy * qz - two * qx * qw;
+    const T r20 = two * qx * qz - two * qy * qw, r21 = two * qy * qz + two * qx * qw, r22 = one - two * qx * qx - two * qy * qy;
+    wx = r00 * bx + r01 * by + r02 * bz;
+    wy = r10 * bx + r11 * by + r12 * bz;
+    wz = r20 * bx + r21 * by + r22 * bz;
+}
+
+template <typename T>
+DYN_HD void ode_quadrotor(const T *X, const T *U, T *dX) {
+    const double m = 1.0, g = 9.81, l = 0.15, Jx = 0.02, Jy = 0.02, Jz = 0.04, kM = 0.01;
+    const T qw = X[6], qx = X[7], qy = X[8], qz = X[9], wx = X[10], wy = X[11], wz = X[12];
+    const T f1 = U[0], f2 = U[1], f3 = U[2], f4 = U[3];
+    const T Fz = f1 + f2 + f3 + f4;
+    T ax, ay, az;
+    rot_apply(qw, qx, qy, qz, T(0.0), T(0.0), Fz, ax, ay, az);
+    dX[0] = X[3]; dX[1] = X[4]; dX[2] = X[5];
+    dX[3] = ax * T(1.0 / m); dX[4] = ay * T(1.0 / m); dX[5] = az * T(1.0 / m) - T(g);
+    // qdot = 0.5 * Omega(omega) q
+    dX[6] = T(0.5) * (-wx * qx - wy * qy - wz * qz);
+    dX[7] = T(0.5) * (wx * qw + wz * qy - wy * qz);
+    dX[8] = T(0.5) * (wy * qw - wz * qx + wx * qz);
+    dX[9] = T(0.5) * (wz * qw + wy * qx - wx * qy);
+    const T tx = T(l) * (f2 - f4), ty = T(l) * (f3 - f1), tz = T(kM) * (f1 - f2 + f3 - f4);
+    // J wdot = tau - w x (J w)
+    const T Jwx = T(Jx) * wx, Jwy = T(Jy) * wy, Jwz = T(Jz) * wz;
+    dX[10] = (tx - (wy * Jwz - wz * Jwy)) * T(1.0 / Jx);
+    dX[11] = (ty - (wz * Jwx - wx * Jwz)) * T(1.0 / Jy);
+    dX[12] = (tz - (wx * Jwy - wy * Jwx)) * T(1.0 / Jz);
+}
+
+template <typename T>
+DYN_HD T gimbal_angle(T servo, T tilt) {   // rocket.py:246-254
+    const double a = 5.0, b = 35.2, c = 33.0, d = 28.0, e = 35.2;
+    const T iv1 = T(d) + T(a) * mcos(servo);
+    const T iv2 = T(e) - T(a) * msin(servo);
+    const T u = T(b * b - c * c) - iv1 * iv1 - iv2 * iv2;
+    const T v = T(2.0 * c) * mcos(tilt) * iv2;
+    const T w = T(-2.0 * c) * iv1;
+    const T iv3 = w * w + v * v - u * u;
+    return T(2.0) * matan((v - msqrt(iv3)) / (u + w));
+}
+
+template <typename T>
+DYN_HD void ode_rocket(const T *X, const T *U, T *dX) {
+    const double mass = 1.16, grav = 9.81, Jxx = 0.00210, Jyy = 0.1, Jzz = 0.1, off = 0.42, tau_t = 0.06, tau_s = 0.10, hover = 11.3796;
+    const T qw = X[6], qx = X[7], qy = X[8], qz = X[9], wx = X[10], wy = X[11], wz = X[12];
+    const T thrust = X[13] + T(hover), torque_x = X[14], sa1 = X[15], sa2 = X[16];
+    const T thrust_in = U[0] + T(hover), torque_in = U[1], sa1_in = U[2], sa2_in = U[3];
+    const T g1 = gimbal_angle(sa1, T(0.0));
+    const T g2 = gimbal_angle(sa2, g1);
+    const T Bx = -thrust * msin(g1) * mcos(g2), By = thrust * msin(g2), Bz = thrust * mcos(g1) * mcos(g2);
+    T ax, ay, az;
+    rot_apply(qw, qx, qy, qz, Bx, By, Bz, ax, ay, az);
+    dX[0] = X[3]; dX[1] = X[4]; dX[2] = X[5];
+    dX[3] = ax * T(1.0 / mass); dX[4] = ay * T(1.0 / mass); dX[5] = az * T(1.0 / mass) - T(grav);
+    dX[6] = T(0.5) * (-wx * qx - wy * qy - wz * qz);
+    dX[7] = T(0.5) * (wx * qw + wz * qy - wy * qz);
+    dX[8] = T(0.5) * (wy * qw - wz * qx + wx * qz);
+    dX[9] = T(0.5) * (wz * qw + wy * qx - wx * qy);
+    // torque = cog_offset x B_thrust with cog_offset = (0,0,-off);  J wdot = torque - w x (J w)   (torque_x state is not fed back: rocket.py:228-231)
+    const T tqx = T(off) * By, tqy = -T(off) * Bx, tqz = T(0.0);
+    const T Jwx = T(Jxx) * wx, Jwy = T(Jyy) * wy, Jwz = T(Jzz) * wz;
+    dX[10] = (tqx - (wy * Jwz - wz * Jwy)) * T(1.0 / Jxx);
+    dX[11] = (tqy - (wz * Jwx - wx * Jwz)) * T(1.0 / Jyy);
+    dX[12] = (tqz - (wx * Jwy - wy * Jwx)) * T(1.0 / Jzz);
+    dX[13] = (thrust_in - thrust) * T(1.0 / tau_t);
+    dX[14] = (torque_in - torque_x) * T(1.0 / tau_t);
+    dX[15] = (sa1_in - sa1) * T(1.0 / tau_s);
+    dX[16] = (sa2_in - sa2) * T(1.0 / tau_s);
+}
+
+template <int MODEL> struct Dims;
+template <> struct Dims<MODEL_PENDULUM> { static constexpr int NX = 4, NU = 1; };
+template <> struct Dims<MODEL_QUADROTOR> { static constexpr int NX = 13, NU = 4; };
+template <> struct Dims<MODEL_ROCKET> { static constexpr int NX = 17, NU = 4; };
+
+template <int MODEL, typename T>
+DYN_HD void ode(const T *X, const T *U, T *dX) {
+    if (MODEL == MODEL_PENDULUM) ode_pendulum<T>(X, U, dX);
+    else if (MODEL == MODEL_QUADROTOR) ode_quadrotor<T>(X, U, dX);
+    else ode_rocket<T>(X, U, dX);
+}
+
+// x+ = RK4(x, u), h = 0.05   (dyn/model.py:27-32); k's are accumulated on the fly to keep the register footprint small
+template <int MODEL, typename T>
+DYN_HD void ddyn(const T *X, const T *U, T *Xp) {
+    constexpr int NX = Dims<MODEL>::NX;
+    const T h(RK4_H);
+    T k[NX], t[NX], acc[NX];
+    ode<MODEL, T>(X, U, k);
+    for (int i = 0; i < NX; i++) { acc[i] = k[i]; t[i] = X[i] + T(0.5) * h * k[i]; }
+    ode<MODEL, T>(t, U, k);
+    for (int i = 0; i < NX; i++) { acc[i] = acc[i] + T(2.0) * k[i]; t[i] = X[i] + T(0.5) * h * k[i]; }
+    ode<MODEL, T>(t, U, k);
+    for (int i = 0; i < NX; i++) { acc[i] = acc[i] + T(2.0) * k[i]; t[i] = X[i] + h * k[i]; }
+    ode<MODEL, T>(t, U, k);
+    for (int i = 0; i < NX; i++) Xp[i] = X[i] + T(1.0 / 6.0) * (acc[i] + k[i]) * h;
+}
+
+// one column of [A B] = d ddyn / d (x,u)_dir by forward-mode AD, plus the value when `f` is given
+template <int MODEL>
+DYN_HD void ddyn_jac_column(const double *x, const double *u, int dir, double *col, double *f) {
+    constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
+    Dual X[NX], U[NU], Xp[NX];
+    for (int i = 0; i < NX; i++) X[i] = Dual(x[i], i == dir ? 1.0 : 0.0);
+    for (int i = 0; i < NU; i++) U[i] = Dual(u[i], NX + i == dir ? 1.0 : 0.0);
+    ddyn<MODEL, Dual>(X, U, Xp);
+    for (int i = 0; i < NX; i++) { col[i] = Xp[i].d; if (f) f[i] = Xp[i].v; }
+}
+
+}  // namespace dyn

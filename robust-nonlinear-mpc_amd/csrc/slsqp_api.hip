@@ -37,7 +37,8 @@ struct slsqp_handle {
     int B, dev, n, m, mb, nz;
     hipStream_t st;
     // problem data
-    double *A, *Bm, *E, *g, *gN, *c, *q, *x0val, *gf_raw, *cst;  // cst: Qd Rd Qfd Qregd Rregd Qregfd packed
+    double *A, *Bm, *E, *g, *gN, *c, *q, *x0val, *gf_raw, *g_raw, *cst;
+    int model_id;  // cst: Qd Rd Qfd Qregd Rregd Qregfd packed
     double *ubg, *lbg;
     // results / state
     double *primal, *dual, *cost, *pin_dual, *kkt, *prev_primal, *Linv, *ws, *qpstate;
@@ -97,7 +98,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     int rc = 0;
     rc |= dalloc(&h->A, B * N * nx * nx); rc |= dalloc(&h->Bm, B * N * nx * nu); rc |= dalloc(&h->E, (size_t)(N + 1) * nx * nw);
     rc |= dalloc(&h->g, B * N * ni); rc |= dalloc(&h->gN, B * nif); rc |= dalloc(&h->c, B * N * nx); rc |= dalloc(&h->q, B * h->n);
-    rc |= dalloc(&h->x0val, B * nx); rc |= dalloc(&h->gf_raw, (size_t)nif); rc |= dalloc(&h->cst, (size_t)(3 * nx + 2 * nu) * 2);
+    rc |= dalloc(&h->x0val, B * nx); rc |= dalloc(&h->gf_raw, (size_t)nif); rc |= dalloc(&h->g_raw, (size_t)ni); rc |= dalloc(&h->cst, (size_t)(3 * nx + 2 * nu) * 2);
     rc |= dalloc(&h->ubg, B * h->mb); rc |= dalloc(&h->lbg, B * h->mb);
     rc |= dalloc(&h->primal, B * h->n); rc |= dalloc(&h->dual, B * h->mb); rc |= dalloc(&h->cost, B); rc |= dalloc(&h->pin_dual, B * nx);
     rc |= dalloc(&h->kkt, B * 8); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx); rc |= dalloc(&h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(&h->qpstate, B * 18);
@@ -132,7 +133,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
         hipMemcpy(h->mapB, mB.data(), mB.size() * sizeof(int), hipMemcpyHostToDevice);
     }
     h->stage = nullptr; h->stage_bytes = 0;
-    h->have_costs = h->have_cons = h->have_dyn = false;
+    h->have_costs = h->have_cons = h->have_dyn = false; h->model_id = -1;
     h->t_total = h->t_qp = h->t_sweep = 0;
     auto reg = [&](const char *nm, void *p, size_t bytes) { h->named[nm] = {p, bytes}; };
     reg("primal_vec", h->primal, sizeof(double) * h->n); reg("dual_vec", h->dual, sizeof(double) * h->mb); reg("cost_nominal", h->cost, sizeof(double));
@@ -143,7 +144,9 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     reg("backoff_x", h->backoff_x, sizeof(double) * (N + 1) * nx); reg("backoff_u", h->backoff_u, sizeof(double) * N * nu);
     reg("eta", h->eta, sizeof(double) * N * N * ni); reg("eta_f", h->eta_f, sizeof(double) * (N + 1) * nif);
     reg("K", h->K, sizeof(double) * N * (N + 1) * nu * nx); reg("ubg", h->ubg, sizeof(double) * h->mb); reg("lbg", h->lbg, sizeof(double) * h->mb);
-    reg("kkt", h->kkt, sizeof(double) * 8); reg("pin_dual", h->pin_dual, sizeof(double) * nx);
+    reg("kkt", h->kkt, sizeof(double) * 8);
+    reg("A", h->A, sizeof(double) * N * nx * nx); reg("Bm", h->Bm, sizeof(double) * N * nx * nu); reg("c", h->c, sizeof(double) * N * nx);
+    reg("g", h->g, sizeof(double) * N * ni); reg("gN", h->gN, sizeof(double) * nif); reg("q", h->q, sizeof(double) * h->n); reg("pin_dual", h->pin_dual, sizeof(double) * nx);
     return h;
 }
 
@@ -151,7 +154,7 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     if (!h) return;
     hipSetDevice(h->dev);
     hipStreamSynchronize(h->st);
-    void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
+    void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->g_raw, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
                     h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->ws, h->qpstate, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
                     h->backoff_u, h->K, h->status, h->iters, h->itnum, h->has_prev, h->conv, h->alive, h->mask, h->success, h->infeas,
                     h->counter, h->mapA, h->mapB};
@@ -433,6 +436,50 @@ extern "C" int slsqp_reset(slsqp_handle *h) {
     HIPCHK(hipMemsetAsync(h->K, 0, sizeof(double) * B * d.N * (d.N + 1) * d.nu * d.nx, h->st));
     HIPCHK(hipStreamSynchronize(h->st));
     h->have_dyn = false;
+    return 0;
+}
+
+
+// ---- linearisation step in front of the path (SCP_SLS.update_jacobian) ----------------------------------------------
+extern "C" int slsqp_set_model(slsqp_handle *h, int model_id, const double *g_raw) {
+    hipSetDevice(h->dev);
+    const int want_nx = model_id == 0 ? 4 : (model_id == 1 ? 13 : (model_id == 2 ? 17 : -1));
+    if (want_nx != h->d.nx) return fail("model id does not match the handle's dimensions (0 pendulum, 1 quadrotor, 2 rocket)");
+    HIPCHK(hipMemcpy(h->g_raw, g_raw, sizeof(double) * h->d.ni, hipMemcpyHostToDevice));
+    h->model_id = model_id;
+    return 0;
+}
+
+extern "C" int slsqp_set_E(slsqp_handle *h, const double *E, int loc) {
+    hipSetDevice(h->dev);
+    return put(h, h->E, E, sizeof(double) * (h->d.N + 1) * h->d.nx * h->d.nw, loc);
+}
+
+extern "C" int slsqp_linearize(slsqp_handle *h, const double *X, const double *U, int loc) {
+    hipSetDevice(h->dev);
+    if (h->model_id < 0 || !h->have_costs || !h->have_cons) return fail("set_model, set_costs and set_constraints must be called first");
+    const slsqp_dims &d = h->d;
+    const size_t B = h->B;
+    const double *dX = X, *dU = U;
+    double *tmp = nullptr;
+    if (loc == SLSQP_HOST) {
+        const size_t nX = B * (d.N + 1) * d.nx, nU = B * d.N * d.nu;
+        HIPCHK(hipMalloc((void **)&tmp, sizeof(double) * (nX + nU)));
+        HIPCHK(hipMemcpy(tmp, X, sizeof(double) * nX, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(tmp + nX, U, sizeof(double) * nU, hipMemcpyHostToDevice));
+        dX = tmp; dU = tmp + nX;
+    }
+    LinArgs a{h->B, d.N, dX, dU, h->g_raw, h->gf_raw, costs_of(h), h->A, h->Bm, h->c, h->g, h->gN, h->q};
+    const int grid = 2048, blk = 128;
+    if (h->model_id == 0) { hipLaunchKernelGGL((k_lin_jac<0>), dim3(grid), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_vec<4, 1>), dim3(grid), dim3(256), 0, h->st, a); }
+    else if (h->model_id == 1) { hipLaunchKernelGGL((k_lin_jac<1>), dim3(grid), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_vec<13, 4>), dim3(grid), dim3(256), 0, h->st, a); }
+    else { hipLaunchKernelGGL((k_lin_jac<2>), dim3(grid), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_vec<17, 4>), dim3(grid), dim3(256), 0, h->st, a); }
+    BoundsArgs ba{h->B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->ubg, h->lbg, 1e-10};
+    hipLaunchKernelGGL(k_set_bounds, dim3(1024), dim3(256), 0, h->st, ba);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->st));
+    if (tmp) hipFree(tmp);
+    h->have_dyn = true;
     return 0;
 }
 

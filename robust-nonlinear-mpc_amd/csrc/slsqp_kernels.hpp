@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "dynamics.hpp"
 #include "wave_la.hpp"
 
 namespace slsqp {
@@ -926,6 +927,53 @@ __global__ void k_init_backoff(InitBackoffArgs a) {
     for (int o = threadIdx.x; o < NIF; o += blockDim.x) a.backoff_f[(size_t)b * NIF + o] = (N + 1) * sq;
     for (int o = threadIdx.x; o < (N + 1) * a.NX; o += blockDim.x) a.backoff_x[(size_t)b * (N + 1) * a.NX + o] = 0.0;
     for (int o = threadIdx.x; o < N * a.NU; o += blockDim.x) a.backoff_u[(size_t)b * N * a.NU + o] = 0.0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Batched linearisation (reference: SCP_SLS.update_jacobian, solver/SCP_SLS_jit.py:251-366):
+//   A_k, B_k = d ddyn / d(x,u) at (x_k,u_k) by forward-mode AD through RK4 (one thread per (instance, stage, direction)),
+//   c_k = ddyn(x_k,u_k) - x_{k+1},  g_k = g - G [x_k;u_k],  g_N = gf - Gf x_N,  q = 2 H y_nom.
+// X (B,N+1,NX), U (B,N,NU) stage-major.
+// ------------------------------------------------------------------------------------------------
+struct LinArgs {
+    int B, N;
+    const double *X, *U, *g_raw, *gf_raw;
+    Costs cst;
+    double *A, *Bm, *c, *g, *gN, *q;
+};
+template <int MODEL>
+__global__ void k_lin_jac(LinArgs a) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU, NZ = NX + NU;
+    const size_t tot = (size_t)a.B * a.N * NZ;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+        const int dir = t % NZ, k = (t / NZ) % a.N, b = t / ((size_t)NZ * a.N);
+        const double *x = a.X + ((size_t)b * (a.N + 1) + k) * NX, *u = a.U + ((size_t)b * a.N + k) * NU;
+        double col[NX], f[NX];
+        dyn::ddyn_jac_column<MODEL>(x, u, dir, col, dir == 0 ? f : nullptr);
+        if (dir < NX) { double *A = a.A + ((size_t)b * a.N + k) * NX * NX; for (int i = 0; i < NX; i++) A[i * NX + dir] = col[i]; }
+        else { double *Bm = a.Bm + ((size_t)b * a.N + k) * NX * NU; for (int i = 0; i < NX; i++) Bm[i * NU + (dir - NX)] = col[i]; }
+        if (dir == 0) { double *c = a.c + ((size_t)b * a.N + k) * NX; for (int i = 0; i < NX; i++) c[i] = f[i] - x[NX + i]; }
+    }
+}
+template <int NX, int NU>
+__global__ void k_lin_vec(LinArgs a) {
+    constexpr int NZ = NX + NU, NI = 2 * NZ, NIF = 2 * NX;
+    const int n = NZ * a.N + NX;
+    const size_t tot = (size_t)a.B * n;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+        const int e = t % n, b = t / n, k = e / NZ, i = e % NZ;
+        const double z = (i < NX) ? a.X[((size_t)b * (a.N + 1) + k) * NX + i] : a.U[((size_t)b * a.N + k) * NU + (i - NX)];
+        if (k < a.N) {
+            double *g = a.g + ((size_t)b * a.N + k) * NI;
+            g[i] = a.g_raw[i] - z; g[NZ + i] = a.g_raw[NZ + i] + z;
+            a.q[t] = 2.0 * (i < NX ? a.cst.Qd[i] : a.cst.Rd[i - NX]) * z;
+        } else {
+            double *g = a.gN + (size_t)b * NIF;
+            g[i] = a.gf_raw[i] - z; g[NX + i] = a.gf_raw[NX + i] + z;
+            a.q[t] = 2.0 * a.cst.Qfd[i] * z;
+        }
+    }
 }
 
 }  // namespace slsqp

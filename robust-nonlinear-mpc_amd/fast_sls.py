@@ -57,6 +57,10 @@ class BatchedFastSLS:
         G, Gf, gf = _c(model.G), _c(model.Gf), _c(model.gf)
         L.check(self.lib.slsqp_set_constraints(self.h, _ptr(G), _ptr(Gf), _ptr(gf)))
         self._E = _c(np.stack([model.E] * (self.N + 1)))
+        if getattr(model, "model_id", None) is not None:
+            g_raw = _c(model.g)
+            L.check(self.lib.slsqp_set_model(self.h, int(model.model_id), _ptr(g_raw)))
+            L.check(self.lib.slsqp_set_E(self.h, _ptr(self._E), L.HOST))
 
     def _push_costs(self):
         L.check(self.lib.slsqp_set_costs(self.h, _ptr(self.Q), _ptr(self.R), _ptr(self.Qf), _ptr(self.Q_reg), _ptr(self.R_reg), _ptr(self.Q_reg_f)))
@@ -90,6 +94,13 @@ class BatchedFastSLS:
             self._E = _c(E)
             assert self._E.shape == (N + 1, m.nx, m.nw)
         L.check(self.lib.slsqp_update_dynamics(self.h, _ptr(A), _ptr(Bm), _ptr(self._E), _ptr(g), _ptr(g_N), _ptr(c), L.HOST))
+
+    def linearize(self, X, U):
+        """Batched SCP_SLS.update_jacobian on the GPU: X (B,N+1,nx), U (B,N,nu) nominal trajectories -> A,B,c,g,q and the
+        un-tightened bounds, all left on the device (SCP_SLS_jit.py:251-366)."""
+        X, U = _c(X), _c(U)
+        assert X.shape == (self.B, self.N + 1, self.m.nx) and U.shape == (self.B, self.N, self.m.nu)
+        L.check(self.lib.slsqp_linearize(self.h, _ptr(X), _ptr(U), L.HOST))
 
     def update_linear_cost(self, q):
         q = _c(q)

@@ -148,3 +148,37 @@ def test_convergence_state_leaks_across_calls_quirk_q5():
     assert np.allclose(out2["backoff"], N * 1e-5)
     assert np.allclose(out2["backoff_x"], 0.0)
     assert np.all(out2["success"])
+
+
+@pytest.mark.parametrize("model", ["pendulum", "quadrotor", "rocket"])
+def test_linearize_vs_reference_dynamics(model):
+    """slsqp_linearize (forward-mode AD through RK4 on the GPU) against the golden fixtures: c_k from the reference's own ddyn
+    values (1e-12), A_k/B_k against central differences of the reference's ddyn (1e-6), g_k, g_N and q by their formulas
+    (SCP_SLS_jit.py:348-366)."""
+    from robust_nonlinear_mpc_amd import BatchedFastSLS, get_model
+    g = dict(np.load(os.path.join(GOLDEN, f"dyn_{model}.npz")))
+    m = get_model(model)
+    P = g["X"].shape[0]
+    N = P - 1 if P - 1 <= 32 else 32
+    B = 2
+    rng = np.random.default_rng(3)
+    X = np.stack([g["X"][: N + 1], g["X"][: N + 1] + 0.01 * rng.normal(size=(N + 1, m.nx))])
+    U = np.stack([g["U"][:N], g["U"][:N] + 0.01 * rng.normal(size=(N, m.nu))])
+    f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=B)
+    f.linearize(X, U)
+    A, Bm, c = f.get("A", (N, m.nx, m.nx)), f.get("Bm", (N, m.nx, m.nu)), f.get("c", (N, m.nx))
+    gk, gN, q = f.get("g", (N, m.ni)), f.get("gN", (m.ni_f,)), f.get("q", (f.n,))
+    ubg = f.get("ubg", (f.mb,))
+    f.close()
+    assert np.allclose(A[0], g["A_fd"][:N], rtol=1e-6, atol=1e-7)
+    assert np.allclose(Bm[0], g["B_fd"][:N], rtol=1e-6, atol=1e-7)
+    assert np.allclose(c[0], g["ddyn"][:N] - g["X"][1: N + 1], rtol=0, atol=1e-12)
+    Z = np.concatenate([X[:, :N], U], axis=2)
+    assert np.allclose(gk, m.g[None, None] - Z @ m.G.T, atol=1e-13)
+    assert np.allclose(gN, m.gf[None] - X[:, N] @ m.Gf.T, atol=1e-13)
+    Hd = np.concatenate([np.concatenate([np.diag(m.Q), np.diag(m.R)])] * N + [np.diag(m.Qf)])
+    ynom = np.concatenate([Z.reshape(B, -1), X[:, N]], axis=1)
+    assert np.allclose(q, 2 * Hd[None] * ynom, atol=1e-12)
+    SR = m.nx + m.ni
+    assert np.allclose(ubg[:, :m.nx], -c[:, 0] + 1e-10, atol=1e-15) and np.allclose(ubg[:, m.nx:SR], gk[:, 0] + 1e-10, atol=1e-14)
+    assert not np.allclose(A[1], A[0])

@@ -18,7 +18,7 @@ def test_cabi_library_exports_every_declared_symbol():
         g.build()
     lib = ctypes.CDLL(_lib.SO_PATH)
     header = open(os.path.join(ROOT, "include", "slsqp.h")).read()
-    declared = set(re.findall(r"\b(slsqp_[a-z_0-9]+)\s*\(", header))
+    declared = set(re.findall(r"\b(slsqp_[A-Za-z_0-9]+)\s*\(", header))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name

@@ -110,6 +110,15 @@ int slsqp_set_model(slsqp_handle *h, int model_id, const double *g_raw);
 int slsqp_set_E(slsqp_handle *h, const double *E, int loc);   /* E (N+1,nx,nw) */
 int slsqp_linearize(slsqp_handle *h, const double *X, const double *U, int loc);
 
+/* ---- the caller after the path: SCP update, warm-start shift, plant step (SCP_SLS.socp_step solver/SCP_SLS_jit.py:404-473,
+   reset_warm_start :500-551, expe/main_rocket_robust_closed_loop.py:149-182) -- a whole closed-loop MPC step with no host round trip.
+   slsqp_cl_init: x_meas (B,nx); X_nom (B,N+1,nx), U_nom (B,N,nu) initial nominal, or NULL,NULL -> roll-out of the plant from x_meas
+   under the constant input u_init (nu) (the reference's IPOPT initialiser is out of scope; pass its result here to reproduce it).
+   slsqp_cl_step: rti SCP iterations (scripts: rocket 1, pendulum/quadrotor 3), w (B,nx) disturbance sample or NULL.
+   Results via slsqp_get: nominal_x (N+1,nx) nominal_u (N,nu) x_meas (nx) u0 (nu) + all names of the fast-SLS result. */
+int slsqp_cl_init(slsqp_handle *h, const double *x_meas, const double *X_nom, const double *U_nom, const double *u_init, int loc);
+int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc, const slsqp_opts *opts);
+
 /* ---- QP-level boundary: mirrors the three calls of the reference's generated module ----------------------- */
 /* P_x (B,nnzP): CSC data of triu(2P) (diagonal => nnzP = n);  A_x (B,nnzA): CSC data of the (m x n) constraint
    matrix INCLUDING the x0-pin rows, sorted indices, pattern of qp_jit.py:77-192 with G=[I;-I]. */

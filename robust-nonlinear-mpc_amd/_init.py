@@ -2,3 +2,4 @@
 from .models import ModelData, pendulum, quadrotor, rocket, get_model  # noqa: F401
 from .fast_sls import BatchedFastSLS, fast_SLS  # noqa: F401,E402
 from .synthetic import make_batch  # noqa: F401,E402
+from .closed_loop import ClosedLoopMPC  # noqa: F401,E402

@@ -1,0 +1,98 @@
+"""Batched closed-loop robust MPC driver on the GPU.
+
+Mirrors what the reference's closed-loop scripts do around `SCP_SLS` for ONE instance
+(expe/main_rocket_robust_closed_loop.py:128-206, main_pendulum...:62-121, main_quadrotor...:98-158), for B instances at once:
+
+    for i in range(steps):
+        if i > 0: solver.reset_warm_start()            SCP_SLS_jit.py:500-551   (shift + solver reset)
+        solution = solver.solve(x0)                     SCP_SLS_jit.py:65-152    (rti x [linearise, fast-SLS, nominal += delta])
+        u0 = solution['primal_u'][:, 0]
+        x0 = m.ddyn(x0, u0) + m.E @ w_i                 plant + bounded noise (rocket only)
+
+Everything between `reset(...)` and the result arrays stays on the device (slsqp_cl_step); the host only supplies the
+disturbance samples.  The reference obtains the very first nominal trajectory from IPOPT (out of scope): pass it as
+`X_nom, U_nom`, or let the driver roll the plant out from x0 under a constant input.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .fast_sls import BatchedFastSLS, _c, _ptr
+
+
+class ClosedLoopMPC:
+    def __init__(self, model, N, batch, rti=None, fast_sls_rti_steps=None, device=0):
+        m = model
+        self.m, self.N, self.B = m, int(N), int(batch)
+        self.rti = int(m.rti if rti is None else rti)
+        self.f = BatchedFastSLS(self.N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=self.B, device=device)
+        self.f.set_rti_steps(m.fast_sls_rti_steps if fast_sls_rti_steps is None else fast_sls_rti_steps)
+        self.steps_done = 0
+
+    def close(self):
+        self.f.close()
+
+    def reset(self, x_meas, X_nom=None, U_nom=None, u_init=None):
+        """x_meas (B,nx).  X_nom (B,N+1,nx), U_nom (B,N,nu) optional initial nominal; else roll-out under `u_init` (default: the
+        model's neutral input)."""
+        f, m = self.f, self.m
+        x_meas = _c(x_meas)
+        assert x_meas.shape == (self.B, m.nx)
+        Xn = None if X_nom is None else _c(X_nom)
+        Un = None if U_nom is None else _c(U_nom)
+        ui = _c(m.u_ref if u_init is None else u_init)
+        L.check(f.lib.slsqp_cl_init(f.h, _ptr(x_meas), _ptr(Xn), _ptr(Un), _ptr(ui), L.HOST))
+        self.steps_done = 0
+
+    def step(self, w=None, fetch=True):
+        """One MPC step of the whole batch.  w (B,nx): disturbance sample in [-1,1]^nx (x+ = ddyn(x,u0) + E w), or None."""
+        f = self.f
+        wv = None if w is None else _c(w)
+        L.check(f.lib.slsqp_cl_step(f.h, self.rti, _ptr(wv), L.HOST, C.byref(f.opts)))
+        self.steps_done += 1
+        if not fetch:
+            return None
+        m, N = self.m, self.N
+        return dict(
+            u0=f.get("u0", (m.nu,)), x_next=f.get("x_meas", (m.nx,)),
+            nominal_x=f.get("nominal_x", (N + 1, m.nx)), nominal_u=f.get("nominal_u", (N, m.nu)),
+            backoff_x=f.get("backoff_x", (N + 1, m.nx)), backoff_u=f.get("backoff_u", (N, m.nu)),
+            success=f.get("success", (), np.int32).astype(bool), status=f.get("status", (), np.int32),
+            t_qp_ms=f.timing_ms()["qp"], t_riccati_ms=f.timing_ms()["sweep"],
+        )
+
+    def run(self, x0, steps, W=None, X_nom=None, U_nom=None):
+        """Closed loop of `steps` MPC steps from x0 (B,nx); W (steps,B,nx) disturbance samples or None.  Returns arrays laid out
+        like the reference's npz (expe/main_rocket_robust_closed_loop.py:189-206) with a leading batch axis."""
+        m, N, B = self.m, self.N, self.B
+        self.reset(x0, X_nom, U_nom)
+        out = dict(
+            state_trajectory=np.zeros((B, m.nx, steps)), input_trajectory=np.zeros((B, m.nu, max(steps - 1, 0))),
+            nominal_trajectory_x=np.zeros((B, m.nx, N + 1, steps)), nominal_trajectory_u=np.zeros((B, m.nu, N, steps)),
+            backoff_trajectory_x=np.zeros((B, m.nx, N + 1, steps)), backoff_trajectory_u=np.zeros((B, m.nu, N, steps)),
+            t_jac=np.full((steps, 1), np.nan), t_qp=np.zeros((steps, 1)), t_riccati=np.zeros((steps, 1)),
+            success=np.zeros((B, steps), dtype=bool),
+        )
+        for i in range(steps):
+            r = self.step(None if W is None else W[i])
+            out["state_trajectory"][:, :, i] = r["nominal_x"][:, 0, :]
+            if i < steps - 1:
+                out["input_trajectory"][:, :, i] = r["u0"]
+            out["nominal_trajectory_x"][:, :, :, i] = r["nominal_x"].transpose(0, 2, 1)
+            out["nominal_trajectory_u"][:, :, :, i] = r["nominal_u"].transpose(0, 2, 1)
+            out["backoff_trajectory_x"][:, :, :, i] = r["backoff_x"].transpose(0, 2, 1)
+            out["backoff_trajectory_u"][:, :, :, i] = r["backoff_u"].transpose(0, 2, 1)
+            out["t_qp"][i], out["t_riccati"][i] = r["t_qp_ms"], r["t_riccati_ms"]
+            out["success"][:, i] = r["success"]
+        return out
+
+    def save_npz(self, path, out, b=0):
+        """Write instance b with exactly the key set the reference's plot()/loaders read (main_rocket...:189-206, 218-241)."""
+        m = self.m
+        steps = out["state_trajectory"].shape[2]
+        np.savez(path, state_trajectory=out["state_trajectory"][b], input_trajectory=out["input_trajectory"][b],
+                 nominal_trajectory_x=out["nominal_trajectory_x"][b], nominal_trajectory_u=out["nominal_trajectory_u"][b],
+                 backoff_trajectory_x=out["backoff_trajectory_x"][b], backoff_trajectory_u=out["backoff_trajectory_u"][b],
+                 dt=0.05, g=m.g, nx=m.nx, nu=m.nu, simulation_time_steps=steps, N=self.N,
+                 t_jac=out["t_jac"], t_qp=out["t_qp"], t_riccati=out["t_riccati"])

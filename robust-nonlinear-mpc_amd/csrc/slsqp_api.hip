@@ -38,7 +38,8 @@ struct slsqp_handle {
     hipStream_t st;
     // problem data
     double *A, *Bm, *E, *g, *gN, *c, *q, *x0val, *gf_raw, *g_raw, *cst;
-    int model_id;  // cst: Qd Rd Qfd Qregd Rregd Qregfd packed
+    int model_id;
+    double *Xn, *Un, *xmeas, *x0arg, *u0, *wbuf, *u_init; int cl_steps;  // cst: Qd Rd Qfd Qregd Rregd Qregfd packed
     double *ubg, *lbg;
     // results / state
     double *primal, *dual, *cost, *pin_dual, *kkt, *prev_primal, *Linv, *ws, *qpstate;
@@ -98,7 +99,9 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     int rc = 0;
     rc |= dalloc(&h->A, B * N * nx * nx); rc |= dalloc(&h->Bm, B * N * nx * nu); rc |= dalloc(&h->E, (size_t)(N + 1) * nx * nw);
     rc |= dalloc(&h->g, B * N * ni); rc |= dalloc(&h->gN, B * nif); rc |= dalloc(&h->c, B * N * nx); rc |= dalloc(&h->q, B * h->n);
-    rc |= dalloc(&h->x0val, B * nx); rc |= dalloc(&h->gf_raw, (size_t)nif); rc |= dalloc(&h->g_raw, (size_t)ni); rc |= dalloc(&h->cst, (size_t)(3 * nx + 2 * nu) * 2);
+    rc |= dalloc(&h->x0val, B * nx); rc |= dalloc(&h->gf_raw, (size_t)nif); rc |= dalloc(&h->g_raw, (size_t)ni);
+    rc |= dalloc(&h->Xn, B * (N + 1) * nx); rc |= dalloc(&h->Un, B * N * nu); rc |= dalloc(&h->xmeas, B * nx); rc |= dalloc(&h->x0arg, B * nx);
+    rc |= dalloc(&h->u0, B * nu); rc |= dalloc(&h->wbuf, B * nx); rc |= dalloc(&h->u_init, (size_t)nu); h->cl_steps = 0; rc |= dalloc(&h->cst, (size_t)(3 * nx + 2 * nu) * 2);
     rc |= dalloc(&h->ubg, B * h->mb); rc |= dalloc(&h->lbg, B * h->mb);
     rc |= dalloc(&h->primal, B * h->n); rc |= dalloc(&h->dual, B * h->mb); rc |= dalloc(&h->cost, B); rc |= dalloc(&h->pin_dual, B * nx);
     rc |= dalloc(&h->kkt, B * 8); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx); rc |= dalloc(&h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(&h->qpstate, B * 18);
@@ -145,6 +148,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     reg("eta", h->eta, sizeof(double) * N * N * ni); reg("eta_f", h->eta_f, sizeof(double) * (N + 1) * nif);
     reg("K", h->K, sizeof(double) * N * (N + 1) * nu * nx); reg("ubg", h->ubg, sizeof(double) * h->mb); reg("lbg", h->lbg, sizeof(double) * h->mb);
     reg("kkt", h->kkt, sizeof(double) * 8);
+    reg("nominal_x", h->Xn, sizeof(double) * (N + 1) * nx); reg("nominal_u", h->Un, sizeof(double) * N * nu); reg("x_meas", h->xmeas, sizeof(double) * nx); reg("u0", h->u0, sizeof(double) * nu);
     reg("A", h->A, sizeof(double) * N * nx * nx); reg("Bm", h->Bm, sizeof(double) * N * nx * nu); reg("c", h->c, sizeof(double) * N * nx);
     reg("g", h->g, sizeof(double) * N * ni); reg("gN", h->gN, sizeof(double) * nif); reg("q", h->q, sizeof(double) * h->n); reg("pin_dual", h->pin_dual, sizeof(double) * nx);
     return h;
@@ -154,7 +158,7 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     if (!h) return;
     hipSetDevice(h->dev);
     hipStreamSynchronize(h->st);
-    void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->g_raw, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
+    void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->g_raw, h->Xn, h->Un, h->xmeas, h->x0arg, h->u0, h->wbuf, h->u_init, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
                     h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->ws, h->qpstate, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
                     h->backoff_u, h->K, h->status, h->iters, h->itnum, h->has_prev, h->conv, h->alive, h->mask, h->success, h->infeas,
                     h->counter, h->mapA, h->mapB};
@@ -480,6 +484,75 @@ extern "C" int slsqp_linearize(slsqp_handle *h, const double *X, const double *U
     HIPCHK(hipStreamSynchronize(h->st));
     if (tmp) hipFree(tmp);
     h->have_dyn = true;
+    return 0;
+}
+
+
+// ---- closed-loop driver around the path (SCP_SLS.solve + reset_warm_start + plant) -------------------------
+static ClArgs cl_args(slsqp_handle *h, const double *w) {
+    ClArgs a;
+    a.B = h->B; a.N = h->d.N; a.NX = h->d.nx; a.NU = h->d.nu; a.Xn = h->Xn; a.Un = h->Un; a.xmeas = h->xmeas; a.primal = h->primal;
+    a.success = h->success; a.x0arg = h->x0arg; a.E = h->E; a.w = w; a.u0 = h->u0; a.u_init = h->u_init;
+    return a;
+}
+
+extern "C" int slsqp_cl_init(slsqp_handle *h, const double *x_meas, const double *X_nom, const double *U_nom, const double *u_init, int loc) {
+    hipSetDevice(h->dev);
+    if (h->model_id < 0) return fail("slsqp_set_model must be called first");
+    const slsqp_dims &d = h->d;
+    const size_t B = h->B;
+    if (put(h, h->xmeas, x_meas, sizeof(double) * B * d.nx, loc)) return -1;
+    if (X_nom && U_nom) {
+        if (put(h, h->Xn, X_nom, sizeof(double) * B * (d.N + 1) * d.nx, loc)) return -1;
+        if (put(h, h->Un, U_nom, sizeof(double) * B * d.N * d.nu, loc)) return -1;
+    } else {
+        std::vector<double> ui(d.nu, 0.0);
+        if (u_init) for (int i = 0; i < d.nu; i++) ui[i] = u_init[i];
+        HIPCHK(hipMemcpy(h->u_init, ui.data(), sizeof(double) * d.nu, hipMemcpyHostToDevice));
+        ClArgs a = cl_args(h, nullptr);
+        const int gb = (h->B + 63) / 64;
+        if (h->model_id == 0) hipLaunchKernelGGL((k_cl_rollout<0>), dim3(gb), dim3(64), 0, h->st, a);
+        else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_rollout<1>), dim3(gb), dim3(64), 0, h->st, a);
+        else hipLaunchKernelGGL((k_cl_rollout<2>), dim3(gb), dim3(64), 0, h->st, a);
+        HIPCHK(hipGetLastError());
+    }
+    h->cl_steps = 0;
+    HIPCHK(hipMemsetAsync(h->has_prev, 0, sizeof(int) * B, h->st));   // a fresh SCP_SLS object has no convergence history
+    HIPCHK(hipStreamSynchronize(h->st));
+    return slsqp_reset(h);
+}
+
+// One MPC step for the whole batch: [warm-start shift + solver reset] -> rti x (linearise, fast-SLS solve of x_nom0 - x_meas,
+// nominal += delta) -> u0 = first nominal input -> plant step x_meas <- ddyn(x_meas,u0) + E w.   w (B,nx) or NULL (no noise).
+extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc, const slsqp_opts *opts) {
+    hipSetDevice(h->dev);
+    if (h->model_id < 0) return fail("slsqp_set_model must be called first");
+    const slsqp_dims &d = h->d;
+    const int gb = (h->B + 63) / 64;
+    const double *dw = nullptr;
+    if (w) { if (put(h, h->wbuf, w, sizeof(double) * (size_t)h->B * d.nx, loc)) return -1; dw = h->wbuf; }
+    ClArgs a = cl_args(h, dw);
+    if (h->cl_steps > 0) {
+        if (h->model_id == 0) hipLaunchKernelGGL((k_cl_shift_plant<0>), dim3(gb), dim3(64), 0, h->st, a, 1, 0);
+        else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_shift_plant<1>), dim3(gb), dim3(64), 0, h->st, a, 1, 0);
+        else hipLaunchKernelGGL((k_cl_shift_plant<2>), dim3(gb), dim3(64), 0, h->st, a, 1, 0);
+        if (slsqp_reset(h)) return -1;
+    }
+    double tq = 0, ts = 0, tt = 0;
+    for (int ii = 0; ii < (rti > 0 ? rti : 1); ii++) {
+        if (slsqp_linearize(h, h->Xn, h->Un, SLSQP_DEVICE)) return -1;
+        hipLaunchKernelGGL(k_cl_x0arg, dim3(64), dim3(256), 0, h->st, a);
+        if (slsqp_solve(h, h->x0arg, SLSQP_DEVICE, opts)) return -1;
+        tq += h->t_qp; ts += h->t_sweep; tt += h->t_total;
+        hipLaunchKernelGGL(k_cl_update, dim3(1024), dim3(256), 0, h->st, a);
+    }
+    if (h->model_id == 0) hipLaunchKernelGGL((k_cl_shift_plant<0>), dim3(gb), dim3(64), 0, h->st, a, 0, 1);
+    else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_shift_plant<1>), dim3(gb), dim3(64), 0, h->st, a, 0, 1);
+    else hipLaunchKernelGGL((k_cl_shift_plant<2>), dim3(gb), dim3(64), 0, h->st, a, 0, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->st));
+    h->t_qp = tq; h->t_sweep = ts; h->t_total = tt;
+    h->cl_steps++;
     return 0;
 }
 

@@ -976,4 +976,85 @@ __global__ void k_lin_vec(LinArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Closed-loop / SCP glue around the path (reference: SCP_SLS.socp_step solver/SCP_SLS_jit.py:404-473,
+// reset_warm_start :500-551, expe/main_rocket_robust_closed_loop.py:149-182).  All elementwise, one thread per item.
+// ------------------------------------------------------------------------------------------------
+struct ClArgs {
+    int B, N, NX, NU;
+    double *Xn, *Un, *xmeas;          // nominal (B,N+1,NX) (B,N,NU), measured state (B,NX)
+    const double *primal;             // (B,n) deviation solution of the last fast-SLS solve
+    const int *success;               // (B)
+    double *x0arg;                    // (B,NX) = x_nom0 - x_meas
+    const double *E, *w;              // E (NX,NX) row-major (stage 0 block), w (B,NX) disturbance sample or NULL
+    double *u0;                       // (B,NU) applied input
+    const double *u_init;             // (NU) input used by the zero-order roll-out initialiser
+};
+// nominal += delta where the step succeeded (SCP_SLS_jit.py:426-430)
+__global__ void k_cl_update(ClArgs a) {
+    const int NZ = a.NX + a.NU, n = NZ * a.N + a.NX;
+    const size_t tot = (size_t)a.B * n;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+        const int e = t % n, b = t / n, k = e / NZ, i = e % NZ;
+        if (!a.success[b]) continue;
+        const double d = a.primal[t];
+        if (i < a.NX) a.Xn[((size_t)b * (a.N + 1) + k) * a.NX + i] += d;
+        else a.Un[((size_t)b * a.N + k) * a.NU + (i - a.NX)] += d;
+    }
+}
+__global__ void k_cl_x0arg(ClArgs a) {
+    const int tot = a.B * a.NX;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += gridDim.x * blockDim.x) {
+        const int b = t / a.NX, i = t % a.NX;
+        a.x0arg[t] = a.Xn[(size_t)b * (a.N + 1) * a.NX + i] - a.xmeas[t];
+    }
+}
+// warm-start shift (SCP_SLS_jit.py:508-518): x_k <- x_{k+1}, u_k <- u_{k+1}, u_{N-1} kept, x_N <- ddyn(x_N, u_{N-1});
+// plant step (expe/main_rocket...:180-182): x_meas <- ddyn(x_meas, u0) + E w.   One thread per instance.
+template <int MODEL>
+__global__ void k_cl_shift_plant(ClArgs a, int do_shift, int do_plant) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    double *X = a.Xn + (size_t)b * (a.N + 1) * NX, *U = a.Un + (size_t)b * a.N * NU;
+    if (do_plant) {
+        double xm[NX], u[NU], xp[NX];
+        for (int i = 0; i < NX; i++) xm[i] = a.xmeas[(size_t)b * NX + i];
+        for (int i = 0; i < NU; i++) { u[i] = U[i]; a.u0[(size_t)b * NU + i] = u[i]; }
+        dyn::ddyn<MODEL, double>(xm, u, xp);
+        for (int i = 0; i < NX; i++) {
+            double s = xp[i];
+            if (a.w) for (int j = 0; j < NX; j++) s += a.E[i * NX + j] * a.w[(size_t)b * NX + j];
+            a.xmeas[(size_t)b * NX + i] = s;
+        }
+    }
+    if (do_shift) {
+        double xN[NX], uN[NU], xp[NX];
+        for (int i = 0; i < NX; i++) xN[i] = X[(size_t)a.N * NX + i];
+        for (int i = 0; i < NU; i++) uN[i] = U[(size_t)(a.N - 1) * NU + i];
+        dyn::ddyn<MODEL, double>(xN, uN, xp);
+        for (int k = 0; k < a.N; k++) for (int i = 0; i < NX; i++) X[(size_t)k * NX + i] = X[(size_t)(k + 1) * NX + i];
+        for (int k = 0; k + 1 < a.N; k++) for (int i = 0; i < NU; i++) U[(size_t)k * NU + i] = U[(size_t)(k + 1) * NU + i];
+        for (int i = 0; i < NX; i++) X[(size_t)a.N * NX + i] = xp[i];
+    }
+}
+// nominal initialiser replacing the reference's IPOPT call for step 0: roll-out of the plant from x_meas under a
+// constant input; callers that have a better nominal pass it to slsqp_cl_init instead.
+template <int MODEL>
+__global__ void k_cl_rollout(ClArgs a) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    double *X = a.Xn + (size_t)b * (a.N + 1) * NX, *U = a.Un + (size_t)b * a.N * NU;
+    double x[NX], u[NU], xp[NX];
+    for (int i = 0; i < NX; i++) { x[i] = a.xmeas[(size_t)b * NX + i]; X[i] = x[i]; }
+    for (int i = 0; i < NU; i++) u[i] = a.u_init[i];
+    for (int k = 0; k < a.N; k++) {
+        for (int i = 0; i < NU; i++) U[(size_t)k * NU + i] = u[i];
+        dyn::ddyn<MODEL, double>(x, u, xp);
+        for (int i = 0; i < NX; i++) { x[i] = xp[i]; X[(size_t)(k + 1) * NX + i] = xp[i]; }
+    }
+}
+
 }  // namespace slsqp

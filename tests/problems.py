@@ -108,3 +108,78 @@ def run_gpu_fastsls(insts, rti_steps=1, solver=None):
     if solver is None:
         f.close()
     return out
+
+
+# ---- closed-loop oracle (restates SCP_SLS.solve / socp_step / reset_warm_start around the oracle fast-SLS) ------------------
+def _dynlib():
+    import ctypes as C
+    import subprocess
+    from conftest import ROOT
+    so = os.path.join(ROOT, "tests", "_build", "libdyn_host.so")
+    src = os.path.join(ROOT, "tests", "dyn_host.cpp")
+    hdr = os.path.join(ROOT, "robust-nonlinear-mpc_amd", "csrc", "dynamics.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    return C.CDLL(so)
+
+
+def host_ddyn(mid, x, u):
+    import ctypes as C
+    lib = _dynlib()
+    x, u, o = np.ascontiguousarray(x, dtype=float), np.ascontiguousarray(u, dtype=float), np.zeros(len(x))
+    lib.dyn_ddyn(mid, x.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p))
+    return o
+
+
+def host_jac(mid, x, u):
+    import ctypes as C
+    lib = _dynlib()
+    x, u = np.ascontiguousarray(x, dtype=float), np.ascontiguousarray(u, dtype=float)
+    A, B, f = np.zeros((len(x), len(x))), np.zeros((len(x), len(u))), np.zeros(len(x))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.dyn_jac(mid, p(x), p(u), p(A), p(B), p(f))
+    return A, B, f
+
+
+def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=None):
+    """Single-instance CPU closed loop: SCP_SLS.solve (solver/SCP_SLS_jit.py:65-152) with the zero-order roll-out initialiser,
+    reset_warm_start (:500-551) and the plant update of the closed-loop scripts."""
+    from oracle import oracle as O
+    d = O.dims_of(m.nx, m.nu, m.nw, N, m.ni, m.ni_f)
+    E = np.stack([m.E] * (N + 1))
+    fs = O.OracleFastSLS(d, m.G, m.Gf, m.g, m.gf, E, m.Q, m.R, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, settings or O.tight_settings())
+    fs.set_rti_steps(sls_steps)
+    mid = m.model_id
+    X = np.zeros((N + 1, m.nx)); U = np.tile(m.u_ref, (N, 1))
+    X[0] = x0
+    for k in range(N):
+        X[k + 1] = host_ddyn(mid, X[k], U[k])
+    Hd = np.concatenate([np.concatenate([np.diag(m.Q), np.diag(m.R)])] * N + [np.diag(m.Qf)])
+    xm = np.asarray(x0, dtype=float).copy()
+    log = dict(state=[], u0=[], nominal_x=[], nominal_u=[], backoff_x=[], success=[])
+    for i in range(steps):
+        if i > 0:
+            xN = host_ddyn(mid, X[N], U[N - 1])
+            X[:N] = X[1:N + 1].copy(); U[:N - 1] = U[1:N].copy(); X[N] = xN
+            fs.reset_solver_to_zeros()
+        ok = True
+        for _ in range(rti):
+            A = np.zeros((N, m.nx, m.nx)); Bm = np.zeros((N, m.nx, m.nu)); c = np.zeros((N, m.nx))
+            for k in range(N):
+                A[k], Bm[k], f = host_jac(mid, X[k], U[k])
+                c[k] = f - X[k + 1]
+            g_list = [m.g - m.G @ np.concatenate([X[k], U[k]]) for k in range(N)] + [m.gf - m.Gf @ X[N]]
+            y_nom = np.concatenate([np.concatenate([X[k], U[k]]) for k in range(N)] + [X[N]])
+            fs.update_dynamics_list(A, Bm, E, g_list, c)
+            fs.update_linear_cost(2.0 * Hd * y_nom)
+            sol = fs.solve(X[0] - xm)
+            ok = bool(sol["success"])
+            if not ok:
+                break
+            X = X + sol["primal_x"].T
+            U = U + sol["primal_u"].T
+        log["state"].append(X[0].copy()); log["u0"].append(U[0].copy()); log["nominal_x"].append(X.copy()); log["nominal_u"].append(U.copy())
+        log["backoff_x"].append(np.array(sol["backoff_x"]) if ok else None); log["success"].append(ok)
+        xm = host_ddyn(mid, xm, U[0]) + (m.E @ W[i] if W is not None else 0.0)
+    return {k: (np.array(v) if k not in ("backoff_x",) else v) for k, v in log.items()}

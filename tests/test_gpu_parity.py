@@ -182,3 +182,31 @@ def test_linearize_vs_reference_dynamics(model):
     SR = m.nx + m.ni
     assert np.allclose(ubg[:, :m.nx], -c[:, 0] + 1e-10, atol=1e-15) and np.allclose(ubg[:, m.nx:SR], gk[:, 0] + 1e-10, atol=1e-14)
     assert not np.allclose(A[1], A[0])
+
+
+@pytest.mark.parametrize("model,N,steps,amp", [("pendulum", 10, 4, 1.0), ("rocket", 20, 2, 0.3)])
+def test_closed_loop_vs_oracle(model, N, steps, amp):
+    """Whole closed-loop MPC steps on the device (linearise -> fast-SLS -> nominal update -> warm-start shift -> plant + noise)
+    against the CPU restatement of SCP_SLS.solve / reset_warm_start built on the oracle; script settings (rti, rti_steps, weights, E)."""
+    from robust_nonlinear_mpc_amd import ClosedLoopMPC, get_model
+    from problems import run_oracle_closed_loop
+    m = get_model(model)
+    B = 3
+    rng = np.random.default_rng(11)
+    x0 = np.stack([m.x_ref + amp * 0.05 * (m.x_ub - m.x_lb) * rng.uniform(-1, 1, m.nx) for _ in range(B)])
+    if model == "pendulum":
+        x0[0] = m.extra["x0"]          # the script's initial state (main_pendulum...:60)
+    W = rng.uniform(-1, 1, (steps, B, m.nx)) if model == "rocket" else None
+    cl = ClosedLoopMPC(m, N, B)
+    out = cl.run(x0, steps, W)
+    cl.close()
+    for b in range(B):
+        ref = run_oracle_closed_loop(m, N, x0[b], steps, m.rti, m.fast_sls_rti_steps, None if W is None else W[:, b])
+        assert list(out["success"][b]) == list(ref["success"])
+        scale = max(1.0, np.abs(ref["nominal_x"]).max())
+        assert np.max(np.abs(out["state_trajectory"][b].T - ref["state"])) < 1e-6 * scale
+        assert np.max(np.abs(out["input_trajectory"][b].T - ref["u0"][: steps - 1])) < 1e-6 * max(1.0, np.abs(ref["u0"]).max())
+        assert np.max(np.abs(out["nominal_trajectory_x"][b].transpose(2, 1, 0) - ref["nominal_x"])) < 1e-6 * scale
+        for i in range(steps):
+            if ref["backoff_x"][i] is not None:
+                assert np.allclose(out["backoff_trajectory_x"][b][:, :, i].T, ref["backoff_x"][i], rtol=1e-5, atol=1e-8)

@@ -142,3 +142,10 @@ def test_shard_and_gather_world_size_2_gloo():
     assert ranges == [(0, 6), (6, 11)]
     for _, _, _, full in res:
         assert full.shape == (11, 3) and np.array_equal(full[:, 0], np.arange(11.0))
+
+
+def test_disturbance_stream_matches_reference_seed0(golden_dir):
+    """np.random.seed(0); w = 2*rand(17)-1 per step (expe/main_rocket_robust_closed_loop.py:30,180)."""
+    from robust_nonlinear_mpc_amd import disturbance_stream
+    W = np.load(os.path.join(golden_dir, "rocket_noise_seed0.npz"))["W"]
+    assert np.array_equal(disturbance_stream(0, 30, 17), W)

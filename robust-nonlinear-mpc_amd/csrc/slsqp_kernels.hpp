@@ -101,7 +101,9 @@ struct NeG {   // global-memory operands of the sweeps (this instance)
 #define STAMP(i) do {} while (0)
 #endif
 template <int NX, int NU>
-__device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool factor, double eflag, double delta, int lane, long long *dbg = nullptr) {
+__device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool factor, double eflag, double delta, int lane, long long *dbg = nullptr,
+                                          double *bmax_out = nullptr) {
+    double bmax = 0.0;
 #ifdef NE_STAMP
     long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
 #endif
@@ -183,6 +185,7 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             }
         }
         if (lane < NX) sT2[lane] = b;
+        bmax = fmax(bmax, fabs(b));
         wla::wsync();
         const double w = wla::matvec_row<NX, NX, false>(Lcur, NX, sT2, lane);   // u_k = Dinv_k t_k
         wla::wsync();
@@ -194,6 +197,7 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
 #ifdef NE_STAMP
     if (dbg && lane == 0) for (int i = 0; i < 8; i++) dbg[i] = acc_[i];
 #endif
+    if (bmax_out) *bmax_out = wla::wave_max(bmax);
     return fail;
 }
 
@@ -312,8 +316,11 @@ __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
     extern __shared__ double sm[];
     const bool factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
     const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
+    double bmax = 0.0;
     const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane,
-                                     (long long *)(a.kkt + (size_t)b * 8));
+                                     (long long *)(a.kkt + (size_t)b * 8), &bmax);
+    // in the refinement solves the right-hand side is E zn - e (+ a vanishing term): the dynamics residual of the polished point
+    if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
     if (lane == 0) { st->ticks += 1.0; if (factor) { st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
 }
 
@@ -544,9 +551,11 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
                 if (ac < 0.0) vsign = fmax(vsign, -gr);    // lambda_l = +gr must be >= 0
             }
             vst = wla::wave_max(vst); vbox = wla::wave_max(vbox); vsign = wla::wave_max(vsign);
-            s.pst = vst; s.pbox = vbox; s.psign = vsign;
+            s.pst = vst; s.psign = vsign;
             const bool pf = s.pol_fail != 0.0;
-            if (!pf && vst < ptol && vbox < ptol && vsign < ptol) {
+            const double eqres = stp->pbox;            // max |E zn - e| seen by the last refinement's forward sweep (before its correction)
+            s.pbox = eqres;
+            if (!pf && vst < ptol && vbox < ptol && vsign < ptol && eqres < 1e-6 * qscale) {
                 polished = true; status = 0; s.kst = vst; s.kbox = vbox; s.ksign = vsign;
                 phase = P_DONE;
             } else if (!pf && vst < ptol && s.pol_round < max_rounds) {

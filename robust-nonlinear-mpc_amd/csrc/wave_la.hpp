@@ -258,6 +258,12 @@ __device__ __forceinline__ int spd_inv_gj(const double *Y, int ld, double *Dinv,
 #pragma unroll
     for (int jb = 0; jb < T; jb++) {
         const int tri_jb = jb * (jb + 1) / 2, dl = tri_jb + jb;
+        // C_I = A_{I,J} (2x2): lane (bi, jb) if bi > jb, else lane (jb, bi) transposed;  C_L = A_{L,J} likewise.  Issued first so the
+        // crossbar round trip overlaps the dependent reciprocal chain of the pivot block below.
+        const int srcI = (bi >= jb) ? tri_bi + jb : tri_jb + bi, srcL = (bj >= jb) ? tri_bj + jb : tri_jb + bj;
+        const double f00 = bperm_d(a00, srcI), f01 = bperm_d(a01, srcI), f10 = bperm_d(a10, srcI), f11 = bperm_d(a11, srcI);
+        const double g00 = bperm_d(a00, srcL), g01 = bperm_d(a01, srcL), g10 = bperm_d(a10, srcL), g11 = bperm_d(a11, srcL);
+        __builtin_amdgcn_sched_barrier(0);
         // pivot block (uniform): P = [[pa, pb],[pb, pc]] from the diagonal lane; P^-1 by two scalar eliminations (as stable as 1x1 pivots)
         const double pa = readlane_d(a00, dl), pb = readlane_d(a10, dl), pc = readlane_d(a11, dl);
         double d1 = pa;
@@ -267,10 +273,6 @@ __device__ __forceinline__ int spd_inv_gj(const double *Y, int ld, double *Dinv,
         if (!(d2 > 1e-300)) { fail = 1; d2 = 1e-300; }
         const double r2 = fast_rcp(d2);
         const double q11 = r2, q01 = -bp * r2, q00 = fma(bp * bp, r2, r1);      // P^-1 = [[q00, q01],[q01, q11]]
-        // C_I = A_{I,J} (2x2): lane (bi, jb) if bi > jb, else lane (jb, bi) transposed;  C_L = A_{L,J} likewise
-        const int srcI = (bi >= jb) ? tri_bi + jb : tri_jb + bi, srcL = (bj >= jb) ? tri_bj + jb : tri_jb + bj;
-        const double f00 = bperm_d(a00, srcI), f01 = bperm_d(a01, srcI), f10 = bperm_d(a10, srcI), f11 = bperm_d(a11, srcI);
-        const double g00 = bperm_d(a00, srcL), g01 = bperm_d(a01, srcL), g10 = bperm_d(a10, srcL), g11 = bperm_d(a11, srcL);
         const bool tI = bi < jb, tL = bj < jb;
         const double ci00 = f00, ci01 = tI ? f10 : f01, ci10 = tI ? f01 : f10, ci11 = f11;
         const double cl00 = g00, cl01 = tL ? g10 : g01, cl10 = tL ? g01 : g10, cl11 = g11;

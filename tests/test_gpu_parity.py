@@ -230,3 +230,85 @@ def test_monte_carlo_seeds_and_npz_keys(tmp_path):
     keys = set(np.load(str(tmp_path / "run.npz")).keys())
     assert keys == {"state_trajectory", "input_trajectory", "nominal_trajectory_x", "nominal_trajectory_u", "backoff_trajectory_x",
                     "backoff_trajectory_u", "dt", "g", "nx", "nu", "simulation_time_steps", "N", "t_jac", "t_qp", "t_riccati"}
+
+
+@pytest.mark.parametrize("model", ["pendulum", "quadrotor"])
+def test_fastsls_converge_mode_vs_oracle(model):
+    """rti_steps <= 0: iterate _step until the primal moves less than 1e-3 (fast_SLS_jit.py:298-312), per-instance stopping."""
+    insts = [make_instance(model, s, a) for a in (0.3, 1.0) for s in range(2)]
+    out = run_gpu_fastsls(insts, rti_steps=0)
+    for b, inst in enumerate(insts):
+        ref = run_oracle_fastsls(inst, rti_steps=None)
+        assert bool(out["success"][b]) == bool(ref["success"])
+        assert out["iteration_number"][b] == ref["iteration_number"]
+        assert relerr(out["primal_vec"][b], ref["primal_vec"]) < 1e-6
+        assert relerr(out["backoff"][b], ref["backoff"]) < 1e-6
+
+
+def test_one_infeasible_instance_does_not_fail_the_batch():
+    """Instance 1 gets a measured state far outside its stage-0 box: the reference's QP is infeasible for it
+    ({'success': False}, qp_jit.py:397-400); the other instances must be unaffected and identical to a clean batch."""
+    insts = [make_instance("pendulum", s, 0.5) for s in range(4)]
+    clean = run_gpu_fastsls(insts, rti_steps=1)
+    bad = [make_instance("pendulum", s, 0.5) for s in range(4)]
+    bad[1].x0_arg = bad[1].x0_arg + 100.0
+    out = run_gpu_fastsls(bad, rti_steps=1)
+    assert not out["success"][1] and out["status"][1] == 2
+    for b in (0, 2, 3):
+        assert out["success"][b]
+        assert np.array_equal(out["primal_vec"][b], clean["primal_vec"][b])
+        assert np.array_equal(out["backoff"][b], clean["backoff"][b])
+
+
+def test_reference_shaped_single_instance_view():
+    """`fast_SLS` (B=1) takes the reference's list arguments and returns the reference's shapes (fast_SLS_jit.py:250-273, 615-643)."""
+    from robust_nonlinear_mpc_amd import fast_SLS
+    inst = make_instance("quadrotor", 0, 0.5)
+    m, N = inst.m, inst.N
+    f = fast_SLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f)
+    f.set_rti_steps(2)
+    f.update_dynamics_list(list(inst.A), list(inst.B), list(inst.E), inst.g_list, [c for c in inst.c])
+    f.update_linear_cost(inst.q.reshape(-1, 1))
+    sol = f.solve(inst.x0_arg)
+    f.close()
+    ref = run_oracle_fastsls(inst, rti_steps=2)
+    assert sol["primal_x"].shape == (m.nx, N + 1) and sol["primal_u"].shape == (m.nu, N)
+    assert sol["dual_mu"].shape == (m.ni, N) and sol["dual_mu_f"].shape == (m.ni_f,)
+    assert sol["eta"].shape == (N, N, m.ni) and sol["K"].shape == (N, N + 1, m.nu, m.nx) and sol["K_mat"].shape == (N * m.nu, (N + 1) * m.nx)
+    assert sol["backoff_x"].shape == (N + 1, m.nx) and sol["backoff_u"].shape == (N, m.nu)
+    assert sol["Phi_x"] is None and np.isnan(sol["cost_tube"])
+    assert bool(sol["success"]) == bool(ref["success"])
+    assert np.allclose(sol["primal_x"], ref["primal_x"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(sol["dual_mu"], ref["dual_mu"], rtol=1e-5, atol=1e-6 * max(1.0, np.abs(ref["dual_mu"]).max()))
+    assert np.allclose(sol["K"], ref["K"], rtol=1e-5, atol=1e-7 * max(1.0, np.abs(ref["K"]).max()))
+
+
+@pytest.mark.parametrize("model,B", [("pendulum", 1024), ("quadrotor", 2048), ("rocket", 4096)])
+def test_full_size_batches_properties(model, B):
+    """BASELINE.json batch sizes: size-independent properties.  Every instance ends with a KKT certificate (status 0), two runs are
+    bit-identical, and an instance's result does not depend on its position in the batch (reverse the batch -> reversed results)."""
+    import os
+    from robust_nonlinear_mpc_amd import BatchedFastSLS, make_batch
+    fx = {"pendulum": "sweep_pendulum_N10_s0.npz", "quadrotor": "sweep_quadrotor_N20_s0.npz", "rocket": "sweep_rocket_N20_s0.npz"}[model]
+    batch = make_batch(model, os.path.join(GOLDEN, fx), B, seed=7)
+    m, N = batch["model"], batch["N"]
+
+    def run(order):
+        f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=B)
+        f.set_rti_steps(1)
+        f.update_dynamics_list(batch["A"][order], batch["B"][order], batch["E"], batch["g"][order], batch["gN"][order], batch["c"][order])
+        f.update_linear_cost(batch["q"][order])
+        f.solve(batch["x0_arg"][order], fetch=False)
+        r = dict(primal=f.get("primal_vec", (f.n,)), backoff=f.get("backoff", (N, m.ni)), status=f.get("status", (), np.int32),
+                 kkt=f.get("kkt", (8,)), success=f.get("success", (), np.int32))
+        f.close()
+        return r
+
+    ident = np.arange(B)
+    r1, r2, r3 = run(ident), run(ident), run(ident[::-1])
+    assert (r1["status"] == 0).all() and r1["success"].all()
+    scale = max(1.0, np.abs(batch["q"]).max())
+    assert r1["kkt"][:, 0].max() < 1e-9 * scale and r1["kkt"][:, 1].max() < 1e-9 * scale and r1["kkt"][:, 2].max() < 1e-9 * scale
+    assert np.array_equal(r1["primal"], r2["primal"]) and np.array_equal(r1["backoff"], r2["backoff"])
+    assert np.array_equal(r1["primal"], r3["primal"][::-1]) and np.array_equal(r1["backoff"], r3["backoff"][::-1])
+    assert (r1["backoff"][:, :, : m.nx] > 0).all()      # tightening really happened

@@ -57,7 +57,8 @@ typedef struct {
                             <=0: converge mode, up to max_sls_iter steps (:298-312) */
     int max_sls_iter;    /* MAX_ITER (30, fast_SLS_jit.py:206) */
     int qp_max_iter;     /* interior-point iteration cap per QP (default 60) */
-    double qp_eps;       /* interior-point residual / complementarity tolerance before polish (default 1e-8) */
+    double qp_eps;       /* interior-point residual / complementarity tolerance before the polish (default 1e-6, relative to max(1,|q|inf));
+                            if the polish then fails to certify, the interior point resumes down to 1e-9 and the polish is repeated */
     double conv_tol;     /* primal convergence test of check_convergence_socp (1e-3, fast_SLS_jit.py:594) */
     double eps_backoff;  /* epsilon_backoff (1e-10, fast_SLS_jit.py:205) */
     int want_K;          /* also keep K (N,N+1,nu,nx) for slsqp_get */

@@ -28,7 +28,7 @@ extern "C" const char *slsqp_last_error(void) { return g_err.c_str(); }
 extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
-    o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-8; o->conv_tol = 1e-3;
+    o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-6; o->conv_tol = 1e-3;
     o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 4;
 }
 
@@ -104,7 +104,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->u0, B * nu); rc |= dalloc(&h->wbuf, B * nx); rc |= dalloc(&h->u_init, (size_t)nu); h->cl_steps = 0; rc |= dalloc(&h->cst, (size_t)(3 * nx + 2 * nu) * 2);
     rc |= dalloc(&h->ubg, B * h->mb); rc |= dalloc(&h->lbg, B * h->mb);
     rc |= dalloc(&h->primal, B * h->n); rc |= dalloc(&h->dual, B * h->mb); rc |= dalloc(&h->cost, B); rc |= dalloc(&h->pin_dual, B * nx);
-    rc |= dalloc(&h->kkt, B * 8); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx); rc |= dalloc(&h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(&h->qpstate, B * 18);
+    rc |= dalloc(&h->kkt, B * 8); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx); rc |= dalloc(&h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(&h->qpstate, B * 20);
     rc |= dalloc(&h->eta, B * N * N * ni); rc |= dalloc(&h->eta_f, B * (N + 1) * nif); rc |= dalloc(&h->beta, B * N * N * ni);
     rc |= dalloc(&h->beta_f, B * (N + 1) * nif); rc |= dalloc(&h->backoff, B * N * ni); rc |= dalloc(&h->backoff_f, B * nif);
     rc |= dalloc(&h->backoff_x, B * (N + 1) * nx); rc |= dalloc(&h->backoff_u, B * N * nu); rc |= dalloc(&h->K, B * N * (N + 1) * nu * nx);

@@ -289,8 +289,8 @@ __device__ __forceinline__ Elem elem_of(int e, int n, int N, const double *ub, c
 // finished instances exit at once.  Splitting the former single kernel removed 340 VGPR + 382 SGPR spills.
 // ------------------------------------------------------------------------------------------------
 enum { P_INIT = 0, P_PRED = 1, P_CORR = 2, P_POL0 = 3, P_POL1 = 4, P_POL2 = 5, P_DONE = 6 };
-struct QpState {   // per instance, 18 doubles
-    double phase, it, status, mu, smu, qscale, mtot, pol_round, pol_fail, warm, kst, kbox, ksign, pst, pbox, psign, ticks, fticks;
+struct QpState {   // per instance, 20 doubles
+    double phase, it, status, mu, smu, qscale, mtot, pol_round, pol_fail, warm, kst, kbox, ksign, pst, pbox, psign, ticks, fticks, tight, pad;
 };
 
 template <int NX, int NU>
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
         if (lane == 0) {
             QpState s0;
             s0.phase = (status == ST_INIT) ? (warm ? P_POL0 : P_INIT) : P_DONE; s0.it = 0; s0.status = status; s0.mu = 0; s0.smu = 0; s0.qscale = qscale;
-            s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1; s0.ticks = 0; s0.fticks = 0;
+            s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1; s0.ticks = 0; s0.fticks = 0; s0.tight = 0; s0.pad = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
             if (status == ST_INIT) atomicAdd(a.n_active, 1);
@@ -395,7 +395,8 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
     int phase = (int)s.phase;
     if (phase == P_DONE) return;
     int status = (int)s.status, it = (int)s.it;
-    const double qscale = s.qscale, mtot = s.mtot, tol = a.eps * qscale, ptol = 1e-9 * qscale;
+    const double qscale = s.qscale, mtot = s.mtot, ptol = 1e-9 * qscale;
+    double tol = (s.tight != 0.0 ? fmin(a.eps, 1e-9) : a.eps) * qscale;
     bool polished = false, start_iter = false;
 
     if (phase == P_INIT) {
@@ -587,6 +588,11 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
                     PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q); Z[e] = z0;
                 }
                 phase = P_INIT;
+            } else if (s.tight == 0.0 && a.eps > 1e-9 && status == 4) {
+                // the interior point stopped at a loose tolerance and its active-set guess did not certify: resume it (its state
+                // arrays are untouched by the polish) down to 1e-9, then polish again
+                s.tight = 1.0; s.pol_round = 0.0; s.pol_fail = 0.0; tol = fmin(a.eps, 1e-9) * qscale;
+                start_iter = true;
             } else phase = P_DONE;
         }
     }

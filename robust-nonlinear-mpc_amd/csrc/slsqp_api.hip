@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -323,6 +324,7 @@ static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int w
     a.cst = costs_of(h); a.Linv = h->Linv; a.ws = h->ws; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
     a.status = h->status; a.iters = h->iters; a.max_iter = o->qp_max_iter; a.eps = o->qp_eps;
     a.state = h->qpstate; a.n_active = h->counter + 1; a.warm = warm; a.warm_rounds = o->warm_rounds;
+    a.init_s = getenv("SLSQP_INIT_S") ? atof(getenv("SLSQP_INIT_S")) : 1.0; a.init_lam = getenv("SLSQP_INIT_LAM") ? atof(getenv("SLSQP_INIT_LAM")) : 0.0;
     if (h->d.nx == 4) return launch_qp_t<4, 1>(h, a, o->qp_max_iter);
     if (h->d.nx == 13) return launch_qp_t<13, 4>(h, a, o->qp_max_iter);
     return launch_qp_t<17, 4>(h, a, o->qp_max_iter);

@@ -66,6 +66,7 @@ struct QpArgs {
     int *status, *iters;      // (B)
     int max_iter;
     double eps;
+    double init_s, init_lam;  // starting slack floor / multiplier of the interior point
     int warm_rounds;          // active-set correction rounds allowed in a warm attempt before falling back
     int warm;                 // 1: try an active-set polish from the previous solution of each instance first
 };
@@ -406,8 +407,10 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
             const double gc = G[e];
             const double z = el.fr ? -(el.q + gc) / el.pd : Z[e];
             GC[e] = gc; Z[e] = z;
-            SU[e] = el.fu ? fmax(el.hi - z, 1.0) : 1.0; LU[e] = el.fu ? 1.0 : 0.0;
-            SL[e] = el.fl ? fmax(z - el.lo, 1.0) : 1.0; LL[e] = el.fl ? 1.0 : 0.0;
+            // starting point: slacks floored at init_s, multipliers init_lam (<= 0: scaled with the linear cost, max(1, 0.1 |q|inf))
+            const double lam0 = a.init_lam > 0.0 ? a.init_lam : fmax(1.0, 0.1 * qscale);
+            SU[e] = el.fu ? fmax(el.hi - z, a.init_s) : 1.0; LU[e] = el.fu ? lam0 : 0.0;
+            SL[e] = el.fl ? fmax(z - el.lo, a.init_s) : 1.0; LL[e] = el.fl ? lam0 : 0.0;
         }
         start_iter = true;
     } else if (phase == P_PRED) {

@@ -306,8 +306,7 @@ static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter) {
             if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
             hipLaunchKernelGGL((k_ne_fwd<NX, NU>), grid, blk, lds, h->st, a);
             if (timed) { hipEventRecord(h->kev[h->n_kev + 1], h->st); h->n_kev += 2; }
-            hipLaunchKernelGGL((k_ne_bwd<NX, NU>), grid, blk, lds, h->st, a);
-            hipLaunchKernelGGL((k_phase<NX, NU>), grid, blk, 0, h->st, a, 0);
+            hipLaunchKernelGGL((k_ne_bwd_phase<NX, NU>), grid, blk, lds, h->st, a);
         }
         HIPCHK(hipMemcpyAsync(&active, a.n_active, sizeof(int), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));

@@ -337,11 +337,9 @@ __global__ __launch_bounds__(64) void k_ne_bwd(QpArgs a) {
 
 // first = 1: set up the instance (x0-pin check, starting rhs); else consume the solve of the current phase.
 template <int NX, int NU>
-__global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
+__device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, int lane) {
     using L = Lay<NX, NU>;
     constexpr int NZ = L::NZ, SR = L::SR;
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B || (a.run && !a.run[b])) return;
     const int N = a.N, n = L::n(N), mb = L::mb(N);
     const double *ub = a.ubg + (size_t)b * mb, *qg = a.q + (size_t)b * n;
     double *ws = a.ws + (size_t)b * qp_ws_doubles(n, N, NX);
@@ -676,6 +674,26 @@ __global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
         }
     }
     if (lane == 0) { s.phase = phase; s.it = it; s.status = status; s.ticks = stp->ticks; s.fticks = stp->fticks; *stp = s; }
+}
+
+template <int NX, int NU>
+__global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B || (a.run && !a.run[b])) return;
+    phase_update<NX, NU>(a, first, b, lane);
+}
+
+// backward sweep fused with the phase update that consumes it (one launch boundary and one pass of idle time less per tick)
+template <int NX, int NU>
+__global__ __launch_bounds__(64) void k_ne_bwd_phase(QpArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B || (a.run && !a.run[b])) return;
+    const QpState *st = (const QpState *)a.state + b;
+    if ((int)st->phase == P_DONE) return;
+    extern __shared__ double sm[];
+    ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
+    wla::wsync_mem();
+    phase_update<NX, NU>(a, 0, b, lane);
 }
 
 // ------------------------------------------------------------------------------------------------

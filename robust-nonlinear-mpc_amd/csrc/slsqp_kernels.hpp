@@ -814,15 +814,29 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
         sS[o] = (i == jj) ? eta_f[j * NIF + i] + eta_f[j * NIF + NX + i] + a.cst.Qregfd[i] : 0.0;
     }
     wla::wsync();
-    for (int k = N - 1; k >= j; k--) {
+    // software pipeline: next stage's A_k, B_k, eta are fetched into registers while the current stage is processed
+    constexpr int RA = (NX * NX + 63) / 64, RB = (NX * NU + 63) / 64;
+    double rA[RA], rB[RB], rC = 0.0;
+    const int lz = min(lane, NZ - 1);
+    const double regd = (lz < NX) ? a.cst.Qregd[lz] : a.cst.Rregd[lz - NX];
+    auto fetch = [&](int k) {
         const double *Ak = gA + (size_t)k * NX * NX, *Bk = gB + (size_t)k * NX * NU;
 #pragma unroll
-        for (int o = lane; o < NX * NX; o += 64) sA[o] = Ak[o];
+        for (int r = 0; r < RA; r++) rA[r] = Ak[min(r * 64 + lane, NX * NX - 1)];
 #pragma unroll
-        for (int o = lane; o < NX * NU; o += 64) sB[o] = Bk[o];
+        for (int r = 0; r < RB; r++) rB[r] = Bk[min(r * 64 + lane, NX * NU - 1)];
         const double *e = eta + ((size_t)k * N + j) * NI;
-        if (lane < NZ) sC[lane] = e[lane] + e[NZ + lane] + (lane < NX ? a.cst.Qregd[lane] : a.cst.Rregd[lane - NX]);
+        rC = e[lz] + e[NZ + lz] + regd;
+    };
+    if (N - 1 >= j) fetch(N - 1);
+    for (int k = N - 1; k >= j; k--) {
+#pragma unroll
+        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < NX * NX) sA[o] = rA[r]; }
+#pragma unroll
+        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) sB[o] = rB[r]; }
+        if (lane < NZ) sC[lane] = rC;
         wla::wsync();
+        if (k - 1 >= j) fetch(k - 1);
         wla::gemm_blk<NU, NX, NX, true, false, 1, 2, false>(sB, NU, sS, NX, sX, NX, 1.0, lane);   // x = B' S   (NU x NX)
         wla::gemm_blk<NX, NX, NX, true, false, 3, 2, false>(sA, NX, sS, NX, sYm, NX, 1.0, lane);  // y = A' S   (NX x NX)
         wla::wsync();
@@ -870,14 +884,23 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
     for (int o = lane; o < NX * NW; o += 64) sPhi[o] = Eg[o];
     wla::wsync();
     double *Pc = sPhi, *Pn = sPhi2;
-    for (int k = j; k < N; k++) {
+    double rK[RB];
+    auto fetch2 = [&](int k) {
         const double *Ak = gA + (size_t)k * NX * NX, *Bk = gB + (size_t)k * NX * NU;
         const double *Kg = gK + ((size_t)k * (N + 1) + j) * NU * NX;
 #pragma unroll
-        for (int o = lane; o < NX * NX; o += 64) sA[o] = Ak[o];
+        for (int r = 0; r < RA; r++) rA[r] = Ak[min(r * 64 + lane, NX * NX - 1)];
 #pragma unroll
-        for (int o = lane; o < NX * NU; o += 64) { sB[o] = Bk[o]; sK[o] = Kg[o]; }
+        for (int r = 0; r < RB; r++) { const int o = min(r * 64 + lane, NX * NU - 1); rB[r] = Bk[o]; rK[r] = Kg[o]; }
+    };
+    if (j < N) fetch2(j);
+    for (int k = j; k < N; k++) {
+#pragma unroll
+        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < NX * NX) sA[o] = rA[r]; }
+#pragma unroll
+        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) { sB[o] = rB[r]; sK[o] = rK[r]; } }
         wla::wsync();
+        if (k + 1 < N) fetch2(k + 1);
         wla::gemm_blk<NU, NW, NX, false, false, 1, 2, false>(sK, NX, Pc, NW, sPu, NW, 1.0, lane);  // Phi_u = K Phi_x
 #pragma unroll
         for (int o = lane; o < NX * NX; o += 64) {

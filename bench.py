@@ -54,16 +54,21 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--model", default="rocket")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from robust_nonlinear_mpc_amd import BatchedFastSLS, make_batch
     from robust_nonlinear_mpc_amd.fast_sls import DeviceBatch
@@ -85,8 +90,9 @@ def main():
     def collect():
         u0 = dev.fetch_device("primal_vec", (f.n,))[:, m.nx:m.nx + m.nu].contiguous()
         if world > 1:
-            gathered = [torch.empty_like(u0) for _ in range(world)]
-            dist.all_gather(gathered, u0)           # RCCL over xGMI: collect the first inputs of every instance
+            src = u0 if args.backend == "nccl" else u0.cpu()
+            gathered = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(gathered, src)          # RCCL over xGMI: collect the first inputs of every instance
             return gathered
         return u0
 
@@ -111,7 +117,7 @@ def main():
     dt = time.perf_counter() - t0
     fwd_total_ms, fwd_launches = f.kernel_timing()
     if world > 1:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     st = f.get("status", (), np.int32)

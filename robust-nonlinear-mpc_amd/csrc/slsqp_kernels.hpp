@@ -204,7 +204,10 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
 
 // Backward sweep: nu_k = u_k - Dinv_k O_{k+1}' nu_{k+1} (overwrites W) and G = E' nu.
 template <int NX, int NU>
-__device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int lane) {
+__device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int lane, long long *dbg = nullptr) {
+#ifdef NE_STAMP
+    long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
     using Ld = QpLds<NX, NU>;
     constexpr int NZ = NX + NU, MM = NX * NX;
     double *sA = sm + Ld::oA, *sLa = sm + Ld::oQ, *sB = sm + Ld::oB, *sPiS = sm + Ld::oPiS, *sWp = sm + Ld::oWp;
@@ -230,12 +233,15 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
         for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) sB[o] = rB[r]; }
         if (lane < NX) { sPiS[lane] = rPi; sWp[lane] = rW; }
         wla::wsync();
+        STAMP(0);
         if (k > 0) prefetch(k - 1);
+        STAMP(1);
         if (lane < NX) sT1[lane] = sPiS[lane] * sT3[lane];
         wla::wsync();
         // nu_k = u_k - Dinv_k O_{k+1}' nu_{k+1} = u_k + Dinv_k (pi_x,k+1 .* A_{k+1}' nu_{k+1})
         const double nu = sWp[lane < NX ? lane : 0] + wla::matvec_row<NX, NX, false>(sLa, NX, sT1, lane);
         wla::wsync();
+        STAMP(2);
         if (lane < NX) {
             g.W[k * NX + lane] = nu;
             g.G[(k + 1) * NZ + lane] = sT3[lane] - nu;
@@ -248,8 +254,12 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
         if (lane < NX) sT3[lane] = ga;
         if (lane < NU) g.G[k * NZ + NX + lane] = gb;
         wla::wsync();
+        STAMP(3);
     }
     if (lane < NX) g.G[lane] = sT3[lane];
+#ifdef NE_STAMP
+    if (dbg && lane == 0) for (int i = 0; i < 4; i++) dbg[i] = acc_[i];
+#endif
 }
 
 // per-element constants of the stage-ordered primal vector, re-read from L2-resident inputs where needed
@@ -319,7 +329,11 @@ __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
     const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
     double bmax = 0.0;
     const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane,
+#ifdef NE_STAMP_BWD
+                                     nullptr, &bmax);
+#else
                                      (long long *)(a.kkt + (size_t)b * 8), &bmax);
+#endif
     // in the refinement solves the right-hand side is E zn - e (+ a vanishing term): the dynamics residual of the polished point
     if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
     if (lane == 0) { st->ticks += 1.0; if (factor) { st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
@@ -360,6 +374,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         const bool warm = a.warm && ((int)stp->status == 0) && ((int)stp->phase == P_DONE) && status == ST_INIT;
         const double *prev = a.primal + (size_t)b * n;
         double qscale = 0.0, mtot = 0.0;
+#pragma unroll 4
         for (int e = lane; e < n; e += 64) {
             const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
             qscale = fmax(qscale, fabs(el.q));
@@ -369,11 +384,11 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 if ((ac > 0.0 && !el.fu) || (ac < 0.0 && !el.fl) || !el.fr) ac = 0.0;
                 const double zp = (e < NX) ? a.x0val[(size_t)b * NX + e] : prev[e];
                 const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zp);
-                const double pi = (el.fr && ac == 0.0) ? 1.0 / el.pd : 0.0;
+                const double pi = (el.fr && ac == 0.0) ? wla::fast_rcp(el.pd) : 0.0;
                 ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
             } else {
                 const double z0 = (e < NX) ? a.x0val[(size_t)b * NX + e] : 0.0;   // rhs of P_INIT: v = z0 - Pi (P z0 + q), z0 = [x0;0]
-                const double pi = el.fr ? 1.0 / el.pd : 0.0;
+                const double pi = el.fr ? wla::fast_rcp(el.pd) : 0.0;
                 PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q); Z[e] = z0;
             }
         }
@@ -400,10 +415,11 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
 
     if (phase == P_INIT) {
         for (int o = lane; o < N * NX; o += 64) NUA[o] = W[o];
+#pragma unroll 4
         for (int e = lane; e < n; e += 64) {
             const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
             const double gc = G[e];
-            const double z = el.fr ? -(el.q + gc) / el.pd : Z[e];
+            const double z = el.fr ? -(el.q + gc) * wla::fast_rcp(el.pd) : Z[e];
             GC[e] = gc; Z[e] = z;
             // starting point: slacks floored at init_s, multipliers init_lam (<= 0: scaled with the linear cost, max(1, 0.1 |q|inf))
             const double lam0 = a.init_lam > 0.0 ? a.init_lam : fmax(1.0, 0.1 * qscale);
@@ -414,21 +430,22 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
     } else if (phase == P_PRED) {
         // affine step: step length, mu_aff = (S0 + a S1 + a^2 S2)/m, second-order terms ds*dlambda
         double amin = 1.0, S0 = 0.0, S1 = 0.0, S2 = 0.0;
+#pragma unroll 4
         for (int e = lane; e < n; e += 64) {
             const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
             const double dz = V[e] - PI[e] * G[e];
             const double z = Z[e], su = SU[e], sl = SL[e], lu = LU[e], ll = LL[e];
             double cu = 0.0, cl = 0.0;
             if (el.fu) {
-                const double ru = z + su - el.hi, dsu = -ru - dz, dlu = -lu + (lu * ru + lu * dz) / su;
-                if (dsu < 0) amin = fmin(amin, -su / dsu);
-                if (dlu < 0) amin = fmin(amin, -lu / dlu);
+                const double ru = z + su - el.hi, dsu = -ru - dz, dlu = -lu + (lu * ru + lu * dz) * wla::fast_rcp(su);
+                if (dsu < 0) amin = fmin(amin, -su * wla::fast_rcp(dsu));
+                if (dlu < 0) amin = fmin(amin, -lu * wla::fast_rcp(dlu));
                 S0 += su * lu; S1 += su * dlu + lu * dsu; cu = dsu * dlu; S2 += cu;
             }
             if (el.fl) {
-                const double rl = el.lo - z + sl, dsl = -rl + dz, dll = -ll + (ll * rl - ll * dz) / sl;
-                if (dsl < 0) amin = fmin(amin, -sl / dsl);
-                if (dll < 0) amin = fmin(amin, -ll / dll);
+                const double rl = el.lo - z + sl, dsl = -rl + dz, dll = -ll + (ll * rl - ll * dz) * wla::fast_rcp(sl);
+                if (dsl < 0) amin = fmin(amin, -sl * wla::fast_rcp(dsl));
+                if (dll < 0) amin = fmin(amin, -ll * wla::fast_rcp(dll));
                 S0 += sl * ll; S1 += sl * dll + ll * dsl; cl = dsl * dll; S2 += cl;
             }
             CU[e] = cu; CL[e] = cl;
@@ -439,36 +456,39 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         double sig = muaff / s.mu; sig = sig * sig * sig;
         const double smu = sig * s.mu;
         s.smu = smu;
+#pragma unroll 4
         for (int e = lane; e < n; e += 64) {
             const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
             const double z = Z[e], su = SU[e], sl = SL[e], lu = LU[e], ll = LL[e];
             double rr = el.fr ? el.pd * z + el.q + GC[e] + lu - ll : 0.0;
-            if (el.fu) rr += (-(su * lu + CU[e] - smu) + lu * (z + su - el.hi)) / su;
-            if (el.fl) rr -= (-(sl * ll + CL[e] - smu) + ll * (el.lo - z + sl)) / sl;
+            if (el.fu) rr += (-(su * lu + CU[e] - smu) + lu * (z + su - el.hi)) * wla::fast_rcp(su);
+            if (el.fl) rr -= (-(sl * ll + CL[e] - smu) + ll * (el.lo - z + sl)) * wla::fast_rcp(sl);
             V[e] = -PI[e] * rr;
         }
         phase = P_CORR;
     } else if (phase == P_CORR) {
         const double smu = s.smu;
         double amin = 1e300;
+#pragma unroll 4
         for (int e = lane; e < n; e += 64) {
             const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
             const double dz = V[e] - PI[e] * G[e];
             const double z = Z[e], su = SU[e], sl = SL[e], lu = LU[e], ll = LL[e];
             if (el.fu) {
                 const double ru = z + su - el.hi, dsu = -ru - dz;
-                const double dlu = (-(su * lu + CU[e] - smu) + lu * ru + lu * dz) / su;
-                if (dsu < 0) amin = fmin(amin, -su / dsu);
-                if (dlu < 0) amin = fmin(amin, -lu / dlu);
+                const double dlu = (-(su * lu + CU[e] - smu) + lu * ru + lu * dz) * wla::fast_rcp(su);
+                if (dsu < 0) amin = fmin(amin, -su * wla::fast_rcp(dsu));
+                if (dlu < 0) amin = fmin(amin, -lu * wla::fast_rcp(dlu));
             }
             if (el.fl) {
                 const double rl = el.lo - z + sl, dsl = -rl + dz;
-                const double dll = (-(sl * ll + CL[e] - smu) + ll * rl - ll * dz) / sl;
-                if (dsl < 0) amin = fmin(amin, -sl / dsl);
-                if (dll < 0) amin = fmin(amin, -ll / dll);
+                const double dll = (-(sl * ll + CL[e] - smu) + ll * rl - ll * dz) * wla::fast_rcp(sl);
+                if (dsl < 0) amin = fmin(amin, -sl * wla::fast_rcp(dsl));
+                if (dll < 0) amin = fmin(amin, -ll * wla::fast_rcp(dll));
             }
         }
         const double alpha = fmin(1.0, 0.99 * wla::wave_min(amin));
+#pragma unroll 4
         for (int e = lane; e < n; e += 64) {
             const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
             const double gg = G[e];
@@ -476,12 +496,12 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             const double z = Z[e], su = SU[e], sl = SL[e], lu = LU[e], ll = LL[e];
             if (el.fu) {
                 const double ru = z + su - el.hi, dsu = -ru - dz;
-                const double dlu = (-(su * lu + CU[e] - smu) + lu * ru + lu * dz) / su;
+                const double dlu = (-(su * lu + CU[e] - smu) + lu * ru + lu * dz) * wla::fast_rcp(su);
                 SU[e] = su + alpha * dsu; LU[e] = lu + alpha * dlu;
             }
             if (el.fl) {
                 const double rl = el.lo - z + sl, dsl = -rl + dz;
-                const double dll = (-(sl * ll + CL[e] - smu) + ll * rl - ll * dz) / sl;
+                const double dll = (-(sl * ll + CL[e] - smu) + ll * rl - ll * dz) * wla::fast_rcp(sl);
                 SL[e] = sl + alpha * dsl; LL[e] = ll + alpha * dll;
             }
             Z[e] = z + alpha * dz; GC[e] += alpha * gg;
@@ -492,6 +512,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
     } else {
         // polish phases: zn = v - Pi g  (v was z0 - Pi r or zn - Pi r1); CU := zn, CL := accumulated E' nu
         const bool firstp = (phase == P_POL0);
+#pragma unroll 4
         for (int e = lane; e < n; e += 64) {
             const double gg = G[e];
             CU[e] = V[e] - PI[e] * gg;
@@ -506,7 +527,8 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             // factorise again, without spending the two refinement solves on a set that is about to change
             const double ctol = 1e-6 * qscale;
             int changed = 0;
-            for (int e = lane; e < n; e += 64) {
+    #pragma unroll 4
+        for (int e = lane; e < n; e += 64) {
                 const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
                 const double zn = CU[e], gr = el.pd * zn + el.q + CL[e], ac = ACT[e];
                 if ((ac > 0.0 && gr > ctol) || (ac < 0.0 && -gr > ctol)) changed = 1;
@@ -515,7 +537,8 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             again = wla::wave_or(changed) != 0;
             if (again) {
                 s.pol_round += 1.0;
-                for (int e = lane; e < n; e += 64) {
+        #pragma unroll 4
+        for (int e = lane; e < n; e += 64) {
                     const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
                     const double zn = CU[e], gr = el.pd * zn + el.q + CL[e];
                     double ac = ACT[e];
@@ -526,7 +549,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                         else if (el.fl && zn < el.lo - ctol) ac = -1.0;
                     }
                     const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zn);
-                    const double pi = (el.fr && ac == 0.0) ? 1.0 / el.pd : 0.0;
+                    const double pi = (el.fr && ac == 0.0) ? wla::fast_rcp(el.pd) : 0.0;
                     ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
                 }
             }
@@ -534,7 +557,8 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         if (again) {
             phase = P_POL0;
         } else if (phase != P_POL2) {
-            for (int e = lane; e < n; e += 64) {
+    #pragma unroll 4
+        for (int e = lane; e < n; e += 64) {
                 const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
                 const double pi = PI[e], zn = CU[e];
                 const double r1 = (pi != 0.0) ? el.pd * zn + el.q + CL[e] : 0.0;
@@ -543,7 +567,8 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             phase = phase + 1;
         } else {
             double vst = 0.0, vbox = 0.0, vsign = 0.0;
-            for (int e = lane; e < n; e += 64) {
+    #pragma unroll 4
+        for (int e = lane; e < n; e += 64) {
                 const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
                 const double zn = CU[e], gr = el.pd * zn + el.q + CL[e], ac = ACT[e];
                 if (el.fr && ac == 0.0) vst = fmax(vst, fabs(gr));
@@ -564,7 +589,8 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 // primal-dual active-set correction: release constraints whose multiplier has the wrong sign,
                 // add violated bounds, factorise again
                 s.pol_round += 1.0;
-                for (int e = lane; e < n; e += 64) {
+        #pragma unroll 4
+        for (int e = lane; e < n; e += 64) {
                     const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
                     const double zn = CU[e], gr = el.pd * zn + el.q + CL[e];
                     double ac = ACT[e];
@@ -575,17 +601,18 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                         else if (el.fl && zn < el.lo - ptol) ac = -1.0;
                     }
                     const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zn);
-                    const double pi = (el.fr && ac == 0.0) ? 1.0 / el.pd : 0.0;
+                    const double pi = (el.fr && ac == 0.0) ? wla::fast_rcp(el.pd) : 0.0;
                     ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
                 }
                 phase = P_POL0;
             } else if (s.warm != 0.0) {
                 // warm attempt failed: cold start of the interior point (rhs of P_INIT)
                 s.warm = 0.0; s.pol_round = 0.0; s.pol_fail = 0.0;
-                for (int e = lane; e < n; e += 64) {
+        #pragma unroll 4
+        for (int e = lane; e < n; e += 64) {
                     const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
                     const double z0 = (e < NX) ? a.x0val[(size_t)b * NX + e] : 0.0;
-                    const double pi = el.fr ? 1.0 / el.pd : 0.0;
+                    const double pi = el.fr ? wla::fast_rcp(el.pd) : 0.0;
                     PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q); Z[e] = z0;
                 }
                 phase = P_INIT;
@@ -602,6 +629,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         wla::wsync_mem();
         // residuals, complementarity, termination test; predictor rhs written in the same pass
         double rmax = 0.0, musum = 0.0;
+#pragma unroll 4
         for (int e = lane; e < n; e += 64) {
             const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
             const double z = Z[e], su = SU[e], sl = SL[e], lu = LU[e], ll = LL[e];
@@ -609,8 +637,8 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             const double ru = el.fu ? z + su - el.hi : 0.0, rl = el.fl ? el.lo - z + sl : 0.0;
             rmax = fmax(rmax, fmax(fabs(rd), fmax(fabs(ru), fabs(rl))));
             musum += (el.fu ? su * lu : 0.0) + (el.fl ? sl * ll : 0.0);
-            const double Wu = el.fu ? lu / su : 0.0, Wl = el.fl ? ll / sl : 0.0;
-            const double pi = el.fr ? 1.0 / (el.pd + Wu + Wl) : 0.0;
+            const double Wu = el.fu ? lu * wla::fast_rcp(su) : 0.0, Wl = el.fl ? ll * wla::fast_rcp(sl) : 0.0;
+            const double pi = el.fr ? wla::fast_rcp(el.pd + Wu + Wl) : 0.0;
             const double tu = el.fu ? -lu + Wu * ru : 0.0, tl = el.fl ? -ll + Wl * rl : 0.0;
             PI[e] = pi; V[e] = -pi * (rd + tu - tl);
         }
@@ -621,13 +649,14 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         else if (res < tol && mu < tol) {
             status = 4;
             // polish rhs: active set, z0 with active entries on their bounds, Pi = 0 there
-            for (int e = lane; e < n; e += 64) {
+    #pragma unroll 4
+        for (int e = lane; e < n; e += 64) {
                 const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
                 const double z = Z[e], lam = LU[e] - LL[e];
                 const bool aU = el.fu && (lam > el.hi - z);
                 const bool aL = el.fl && !aU && (-lam > z - el.lo);
                 const double z0 = aU ? el.hi : (aL ? el.lo : z);
-                const double pi = (el.fr && !aU && !aL) ? 1.0 / el.pd : 0.0;
+                const double pi = (el.fr && !aU && !aL) ? wla::fast_rcp(el.pd) : 0.0;
                 ACT[e] = aU ? 1.0 : (aL ? -1.0 : 0.0); PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
             }
             phase = P_POL0;
@@ -642,7 +671,8 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         double csum = 0.0;
         const bool ok = (status == 0 || status == 4);   // on failure the previous primal/dual stay (fast_SLS_jit.py:461-464)
         if (ok) {
-            for (int e = lane; e < n; e += 64) {
+    #pragma unroll 4
+        for (int e = lane; e < n; e += 64) {
                 const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
                 double zv, yu, yl, gv;
                 if (polished) {
@@ -691,9 +721,21 @@ __global__ __launch_bounds__(64) void k_ne_bwd_phase(QpArgs a) {
     const QpState *st = (const QpState *)a.state + b;
     if ((int)st->phase == P_DONE) return;
     extern __shared__ double sm[];
+#ifdef NE_STAMP
+    long long *dbg = (long long *)(a.kkt + (size_t)b * 8);
+    const long long t0_ = __builtin_readcyclecounter();
+    ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane, (int)st->phase == P_INIT ? dbg : nullptr);
+    wla::wsync_mem();
+    const long long t1_ = __builtin_readcyclecounter();
+    const bool rec = (int)st->phase == P_INIT;
+    phase_update<NX, NU>(a, 0, b, lane);
+    wla::wsync_mem();
+    if (rec && lane == 0) { dbg[4] = t1_ - t0_; dbg[5] = __builtin_readcyclecounter() - t1_; }
+#else
     ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
     wla::wsync_mem();
     phase_update<NX, NU>(a, 0, b, lane);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -65,6 +65,8 @@ typedef struct {
     int warm_start;      /* 1 (default): the first QP of a call first tries an active-set polish from the instance's previous
                             certified solution (KKT-verified, falls back to the interior point); later QPs of a call always do */
     int warm_rounds;     /* active-set correction rounds a warm attempt may use before falling back (default 4) */
+    int max_scp_iter;    /* MAX_ITER_SCP (100, SCP_SLS_jit.py:47): cap of the SCP loop of slsqp_cl_step in converge mode (rti <= 0) */
+    double scp_eps;      /* epsilon_convergence (1e-10, SCP_SLS_jit.py:29): SCP converged when |delta_vec|inf < scp_eps */
 } slsqp_opts;
 
 void slsqp_default_opts(slsqp_opts *o);
@@ -103,7 +105,7 @@ int slsqp_reset(slsqp_handle *h);
 int slsqp_sync(slsqp_handle *h);
 
 /* ---- the step in front of the path: batched linearisation (SCP_SLS.update_jacobian, solver/SCP_SLS_jit.py:251-366) ---------
-   model_id: 0 pendulum, 1 quadrotor, 2 rocket (dyn/*.py ODEs, RK4 h=0.05, dyn/model.py:15-34); g_raw (ni): the plant's stage bound g.
+   model_id: 0 pendulum, 1 quadrotor, 2 rocket (ODEs of dyn/{pendulum,quadrotor,rocket}.py, RK4 h=0.05, dyn/model.py:15-34); g_raw (ni): the plant's stage bound g.
    slsqp_linearize: X (B,N+1,nx), U (B,N,nu) nominal trajectories (stage-major) -> A,B (forward-mode AD through RK4),
    c_k = f(x_k,u_k) - x_{k+1}, g_k = g - G[x_k;u_k], g_N = gf - Gf x_N, q = 2 H y_nom, then the un-tightened bounds; E is untouched
    (set it once with slsqp_update_dynamics or slsqp_set_E). Equivalent to update_dynamics + update_linear_cost. */
@@ -115,8 +117,11 @@ int slsqp_linearize(slsqp_handle *h, const double *X, const double *U, int loc);
    reset_warm_start :500-551, expe/main_rocket_robust_closed_loop.py:149-182) -- a whole closed-loop MPC step with no host round trip.
    slsqp_cl_init: x_meas (B,nx); X_nom (B,N+1,nx), U_nom (B,N,nu) initial nominal, or NULL,NULL -> roll-out of the plant from x_meas
    under the constant input u_init (nu) (the reference's IPOPT initialiser is out of scope; pass its result here to reproduce it).
-   slsqp_cl_step: rti SCP iterations (scripts: rocket 1, pendulum/quadrotor 3), w (B,nx) disturbance sample or NULL.
-   Results via slsqp_get: nominal_x (N+1,nx) nominal_u (N,nu) x_meas (nx) u0 (nu) + all names of the fast-SLS result. */
+   slsqp_cl_step: rti > 0: exactly rti SCP iterations (scripts: rocket 1, pendulum/quadrotor 3); rti <= 0: SCP_SLS's default
+   converge mode (rti = -1, SCP_SLS_jit.py:20-21,113-135): iterate every instance until |delta_vec|inf < opts.scp_eps, at most
+   opts.max_scp_iter times; an instance whose fast-SLS step fails leaves the loop (:118-119).  w (B,nx) disturbance sample or NULL.
+   Results via slsqp_get: nominal_x (N+1,nx) nominal_u (N,nu) x_meas (nx) u0 (nu) scp_success[int32] (1) scp_iterations[int32] (1)
+   scp_delta_max (1) + all names of the fast-SLS result (for each instance: of its last fast-SLS solve). */
 int slsqp_cl_init(slsqp_handle *h, const double *x_meas, const double *X_nom, const double *U_nom, const double *u_init, int loc);
 int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc, const slsqp_opts *opts);
 

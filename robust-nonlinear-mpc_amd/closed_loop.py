@@ -27,7 +27,11 @@ class ClosedLoopMPC:
         self.m, self.N, self.B = m, int(N), int(batch)
         self.rti = int(m.rti if rti is None else rti)
         self.f = BatchedFastSLS(self.N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=self.B, device=device)
-        self.f.set_rti_steps(m.fast_sls_rti_steps if fast_sls_rti_steps is None else fast_sls_rti_steps)
+        # rti > 0: that many SCP iterations per MPC step (scripts); rti <= 0: SCP_SLS's default converge mode (SCP_SLS_jit.py:20-21).
+        # fast_sls_rti_steps: None -> the script's value when rti is the script's, the reference default (converge, None) otherwise
+        if fast_sls_rti_steps is None and rti is None:
+            fast_sls_rti_steps = m.fast_sls_rti_steps
+        self.f.set_rti_steps(fast_sls_rti_steps)
         self.steps_done = 0
 
     def close(self):
@@ -58,7 +62,8 @@ class ClosedLoopMPC:
             u0=f.get("u0", (m.nu,)), x_next=f.get("x_meas", (m.nx,)),
             nominal_x=f.get("nominal_x", (N + 1, m.nx)), nominal_u=f.get("nominal_u", (N, m.nu)),
             backoff_x=f.get("backoff_x", (N + 1, m.nx)), backoff_u=f.get("backoff_u", (N, m.nu)),
-            success=f.get("success", (), np.int32).astype(bool), status=f.get("status", (), np.int32),
+            success=f.get("scp_success", (), np.int32).astype(bool), status=f.get("status", (), np.int32),
+            scp_iterations=f.get("scp_iterations", (), np.int32),
             t_qp_ms=f.timing_ms()["qp"], t_riccati_ms=f.timing_ms()["sweep"],
         )
 
@@ -72,7 +77,7 @@ class ClosedLoopMPC:
             nominal_trajectory_x=np.zeros((B, m.nx, N + 1, steps)), nominal_trajectory_u=np.zeros((B, m.nu, N, steps)),
             backoff_trajectory_x=np.zeros((B, m.nx, N + 1, steps)), backoff_trajectory_u=np.zeros((B, m.nu, N, steps)),
             t_jac=np.full((steps, 1), np.nan), t_qp=np.zeros((steps, 1)), t_riccati=np.zeros((steps, 1)),
-            success=np.zeros((B, steps), dtype=bool),
+            success=np.zeros((B, steps), dtype=bool), scp_iterations=np.zeros((B, steps), dtype=np.int32),
         )
         for i in range(steps):
             r = self.step(None if W is None else W[i])
@@ -85,6 +90,7 @@ class ClosedLoopMPC:
             out["backoff_trajectory_u"][:, :, :, i] = r["backoff_u"].transpose(0, 2, 1)
             out["t_qp"][i], out["t_riccati"][i] = r["t_qp_ms"], r["t_riccati_ms"]
             out["success"][:, i] = r["success"]
+            out["scp_iterations"][:, i] = r["scp_iterations"]
         return out
 
     def save_npz(self, path, out, b=0):

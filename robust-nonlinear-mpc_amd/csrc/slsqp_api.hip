@@ -31,6 +31,7 @@ extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
     o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-6; o->conv_tol = 1e-3;
     o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 4;
+    o->max_scp_iter = 100; o->scp_eps = 1e-10;
 }
 
 struct slsqp_handle {
@@ -46,6 +47,7 @@ struct slsqp_handle {
     double *primal, *dual, *cost, *pin_dual, *kkt, *prev_primal, *Linv, *ws, *qpstate;
     double *eta, *eta_f, *beta, *beta_f, *backoff, *backoff_f, *backoff_x, *backoff_u, *K;
     int *status, *iters, *itnum, *has_prev, *conv, *alive, *mask, *success, *infeas, *counter;
+    int *scp_active, *scp_success, *scp_iters, *pending_reset; double *scp_dmax;
     // qp-level CSC maps
     int *mapA, *mapB;  // CSC offsets of A_k[i][j] / B_k[i][j]
     double *stage;     // staging buffer for host<->device transfers
@@ -111,6 +113,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->backoff_x, B * (N + 1) * nx); rc |= dalloc(&h->backoff_u, B * N * nu); rc |= dalloc(&h->K, B * N * (N + 1) * nu * nx);
     rc |= dalloc(&h->status, B); rc |= dalloc(&h->iters, B); rc |= dalloc(&h->itnum, B); rc |= dalloc(&h->has_prev, B); rc |= dalloc(&h->conv, B);
     rc |= dalloc(&h->alive, B); rc |= dalloc(&h->mask, B); rc |= dalloc(&h->success, B); rc |= dalloc(&h->infeas, B); rc |= dalloc(&h->counter, (size_t)4);
+    rc |= dalloc(&h->scp_active, B); rc |= dalloc(&h->scp_success, B); rc |= dalloc(&h->scp_iters, B); rc |= dalloc(&h->pending_reset, B); rc |= dalloc(&h->scp_dmax, B);
     rc |= dalloc(&h->mapA, (size_t)N * nx * nx); rc |= dalloc(&h->mapB, (size_t)N * nx * nu);
     if (rc) { delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
@@ -142,7 +145,8 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     auto reg = [&](const char *nm, void *p, size_t bytes) { h->named[nm] = {p, bytes}; };
     reg("primal_vec", h->primal, sizeof(double) * h->n); reg("dual_vec", h->dual, sizeof(double) * h->mb); reg("cost_nominal", h->cost, sizeof(double));
     reg("status", h->status, sizeof(int)); reg("qp_iters", h->iters, sizeof(int)); reg("iteration_number", h->itnum, sizeof(int));
-    reg("success", h->success, sizeof(int));
+    reg("success", h->success, sizeof(int)); reg("scp_success", h->scp_success, sizeof(int)); reg("scp_iterations", h->scp_iters, sizeof(int));
+    reg("scp_delta_max", h->scp_dmax, sizeof(double));
     reg("beta", h->beta, sizeof(double) * N * N * ni); reg("beta_f", h->beta_f, sizeof(double) * (N + 1) * nif);
     reg("backoff", h->backoff, sizeof(double) * N * ni); reg("backoff_f", h->backoff_f, sizeof(double) * nif);
     reg("backoff_x", h->backoff_x, sizeof(double) * (N + 1) * nx); reg("backoff_u", h->backoff_u, sizeof(double) * N * nu);
@@ -162,7 +166,7 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->g_raw, h->Xn, h->Un, h->xmeas, h->x0arg, h->u0, h->wbuf, h->u_init, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
                     h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->ws, h->qpstate, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
                     h->backoff_u, h->K, h->status, h->iters, h->itnum, h->has_prev, h->conv, h->alive, h->mask, h->success, h->infeas,
-                    h->counter, h->mapA, h->mapB};
+                    h->counter, h->mapA, h->mapB, h->scp_active, h->scp_success, h->scp_iters, h->pending_reset, h->scp_dmax};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : h->ev) hipEventDestroy(e);
     for (auto &e : h->kev) hipEventDestroy(e);
@@ -228,7 +232,7 @@ extern "C" int slsqp_update_dynamics(slsqp_handle *h, const double *A, const dou
     if (put(h, h->g, g, sizeof(double) * B * d.N * d.ni, loc)) return -1;
     if (put(h, h->gN, g_N, sizeof(double) * B * d.ni_f, loc)) return -1;
     if (put(h, h->c, c, sizeof(double) * B * d.N * d.nx, loc)) return -1;
-    BoundsArgs a{h->B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->ubg, h->lbg, 1e-10};
+    BoundsArgs a{h->B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->ubg, h->lbg, 1e-10, nullptr};
     hipLaunchKernelGGL(k_set_bounds, dim3(1024), dim3(256), 0, h->st, a);
     HIPCHK(hipGetLastError());
     h->have_dyn = true;
@@ -260,12 +264,25 @@ __global__ void k_post_conv(int B, int rti, const int *conv, int *alive, int *ma
     mask[b] = m;
     if (m) { itnum[b] += 1; atomicAdd(counter, 1); }
 }
-__global__ void k_finish(int B, int rti, const int *alive, const int *infeas, int *success) {
+__global__ void k_finish(int B, int rti, const int *alive, const int *infeas, int *success, const int *active, int *pending_reset) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (active && !active[b]) { success[b] = 0; return; }       // not part of this call
     if (rti) success[b] = (!infeas[b]) || success[b];           // fast_SLS_jit.py:295
-    else if (alive[b] || infeas[b]) success[b] = 0;             // hit MAX_ITER or infeasible (:304, :312)
+    else if (alive[b] || infeas[b]) { success[b] = 0; pending_reset[b] = 1; }   // hit MAX_ITER or infeasible (:304, :312) -> _finish_failure
 }
+// _finish_failure (fast_SLS_jit.py:334-341) resets the solver AFTER the result dict has been built: the reset (eta, eta_f,
+// iteration_number -> 0; bounds and linear cost are rewritten by the caller's next update anyway) is applied at the top of the
+// instance's next solve, so that slsqp_get still returns the failed call's arrays.
+__global__ void k_apply_pending_reset(int B, int *pending, const int *active, int *itnum, double *eta, size_t neta, double *eta_f, size_t netaf) {
+    const int b = blockIdx.x;
+    if (!pending[b] || (active && !active[b])) return;
+    for (size_t o = threadIdx.x; o < neta; o += blockDim.x) eta[(size_t)b * neta + o] = 0.0;
+    for (size_t o = threadIdx.x; o < netaf; o += blockDim.x) eta_f[(size_t)b * netaf + o] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) { itnum[b] = 0; pending[b] = 0; }
+}
+__global__ void k_copy_int(const int *src, int *dst, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[i]; }
 __global__ void k_split_lu(int B, int mb, int nx, const double *l, const double *u, double *lbg, double *ubg, double *x0val) {
     const int m = mb + nx;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < (size_t)B * m; idx += (size_t)gridDim.x * blockDim.x) {
@@ -347,7 +364,8 @@ static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, cons
 
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
 
-extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts) {
+// `active` (device, B ints or NULL = all): instances that take part in this call; the others keep every result array untouched.
+static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts, const int *active) {
     hipSetDevice(h->dev);
     if (!h->have_costs || !h->have_cons || !h->have_dyn) return fail("set_costs, set_constraints and update_dynamics must be called first");
     slsqp_opts o;
@@ -366,11 +384,14 @@ extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const sls
     const int steps = rti ? o.rti_steps : o.max_sls_iter;
     std::vector<float> tq, ts;
     HIPCHK(hipEventRecord(h->ev[0], h->st));
-    hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->alive, 1, B);
+    if (active) hipLaunchKernelGGL(k_copy_int, dim3(gb), dim3(256), 0, h->st, active, h->alive, B);
+    else hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->alive, 1, B);
+    hipLaunchKernelGGL(k_apply_pending_reset, dim3(B), dim3(256), 0, h->st, B, h->pending_reset, active, h->itnum, h->eta, (size_t)d.N * d.N * d.ni, h->eta_f,
+                       (size_t)(d.N + 1) * d.ni_f);
     hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->infeas, 0, B);
     hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->success, 0, B);
     {   // initialize_backoff at the top of every solve (fast_SLS_jit.py:281,299)
-        InitBackoffArgs ia{B, d.N, d.nx, d.nu, o.eps_backoff, nullptr, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u};
+        InitBackoffArgs ia{B, d.N, d.nx, d.nu, o.eps_backoff, active, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u};
         hipLaunchKernelGGL(k_init_backoff, dim3(B), dim3(256), 0, h->st, ia);
     }
     double acc_qp = 0, acc_sw = 0;
@@ -400,13 +421,15 @@ extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const sls
     HIPCHK(hipEventRecord(h->ev[1], h->st));
     if (launch_qp(h, h->alive, &o, 1)) return -1;
     HIPCHK(hipEventRecord(h->ev[2], h->st));
-    hipLaunchKernelGGL(k_finish, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->alive, h->infeas, h->success);
+    hipLaunchKernelGGL(k_finish, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->alive, h->infeas, h->success, active, h->pending_reset);
     HIPCHK(hipEventRecord(h->ev[5], h->st));
     HIPCHK(hipStreamSynchronize(h->st));
     acc_qp += ev_ms(h->ev[1], h->ev[2]);
     h->t_total = ev_ms(h->ev[0], h->ev[5]); h->t_qp = acc_qp; h->t_sweep = acc_sw;
     return 0;
 }
+
+extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts) { return solve_impl(h, x0, loc, opts, nullptr); }
 
 extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms4) {
     ms4[0] = h->t_total; ms4[1] = h->t_qp; ms4[2] = h->t_sweep; ms4[3] = h->t_total - h->t_qp - h->t_sweep;
@@ -437,6 +460,7 @@ extern "C" int slsqp_reset(slsqp_handle *h) {
     HIPCHK(hipMemsetAsync(h->eta, 0, sizeof(double) * B * d.N * d.N * d.ni, h->st));
     HIPCHK(hipMemsetAsync(h->eta_f, 0, sizeof(double) * B * (d.N + 1) * d.ni_f, h->st));
     HIPCHK(hipMemsetAsync(h->itnum, 0, sizeof(int) * B, h->st));
+    HIPCHK(hipMemsetAsync(h->pending_reset, 0, sizeof(int) * B, h->st));
     HIPCHK(hipMemsetAsync(h->q, 0, sizeof(double) * B * h->n, h->st));
     HIPCHK(hipMemsetAsync(h->K, 0, sizeof(double) * B * d.N * (d.N + 1) * d.nu * d.nx, h->st));
     HIPCHK(hipStreamSynchronize(h->st));
@@ -460,7 +484,7 @@ extern "C" int slsqp_set_E(slsqp_handle *h, const double *E, int loc) {
     return put(h, h->E, E, sizeof(double) * (h->d.N + 1) * h->d.nx * h->d.nw, loc);
 }
 
-extern "C" int slsqp_linearize(slsqp_handle *h, const double *X, const double *U, int loc) {
+static int linearize_impl(slsqp_handle *h, const double *X, const double *U, int loc, const int *run) {
     hipSetDevice(h->dev);
     if (h->model_id < 0 || !h->have_costs || !h->have_cons) return fail("set_model, set_costs and set_constraints must be called first");
     const slsqp_dims &d = h->d;
@@ -474,12 +498,12 @@ extern "C" int slsqp_linearize(slsqp_handle *h, const double *X, const double *U
         HIPCHK(hipMemcpy(tmp + nX, U, sizeof(double) * nU, hipMemcpyHostToDevice));
         dX = tmp; dU = tmp + nX;
     }
-    LinArgs a{h->B, d.N, dX, dU, h->g_raw, h->gf_raw, costs_of(h), h->A, h->Bm, h->c, h->g, h->gN, h->q};
+    LinArgs a{h->B, d.N, dX, dU, h->g_raw, h->gf_raw, costs_of(h), h->A, h->Bm, h->c, h->g, h->gN, h->q, run};
     const int grid = 2048, blk = 128;
     if (h->model_id == 0) { hipLaunchKernelGGL((k_lin_jac<0>), dim3(grid), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_vec<4, 1>), dim3(grid), dim3(256), 0, h->st, a); }
     else if (h->model_id == 1) { hipLaunchKernelGGL((k_lin_jac<1>), dim3(grid), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_vec<13, 4>), dim3(grid), dim3(256), 0, h->st, a); }
     else { hipLaunchKernelGGL((k_lin_jac<2>), dim3(grid), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_vec<17, 4>), dim3(grid), dim3(256), 0, h->st, a); }
-    BoundsArgs ba{h->B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->ubg, h->lbg, 1e-10};
+    BoundsArgs ba{h->B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->ubg, h->lbg, 1e-10, run};
     hipLaunchKernelGGL(k_set_bounds, dim3(1024), dim3(256), 0, h->st, ba);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->st));
@@ -487,6 +511,7 @@ extern "C" int slsqp_linearize(slsqp_handle *h, const double *X, const double *U
     h->have_dyn = true;
     return 0;
 }
+extern "C" int slsqp_linearize(slsqp_handle *h, const double *X, const double *U, int loc) { return linearize_impl(h, X, U, loc, nullptr); }
 
 
 // ---- closed-loop driver around the path (SCP_SLS.solve + reset_warm_start + plant) -------------------------
@@ -540,12 +565,30 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
         if (slsqp_reset(h)) return -1;
     }
     double tq = 0, ts = 0, tt = 0;
-    for (int ii = 0; ii < (rti > 0 ? rti : 1); ii++) {
-        if (slsqp_linearize(h, h->Xn, h->Un, SLSQP_DEVICE)) return -1;
+    slsqp_opts o;
+    if (opts) o = *opts; else slsqp_default_opts(&o);
+    // SCP_SLS.solve (solver/SCP_SLS_jit.py:65-152): rti > 0 -> exactly rti iterations; rti <= 0 -> until |delta|inf < scp_eps
+    // (epsilon_convergence :29) or MAX_ITER_SCP (:47).  Instances leave the loop one by one (failed step / converged); the
+    // linearisation, the fast-SLS solve and the nominal update only touch the ones still iterating.
+    const bool converge = rti <= 0;
+    const int max_it = converge ? o.max_scp_iter : rti;
+    const int B = h->B, gbi = (B + 255) / 256;
+    hipLaunchKernelGGL(k_fill_int, dim3(gbi), dim3(256), 0, h->st, h->scp_active, 1, B);
+    hipLaunchKernelGGL(k_fill_int, dim3(gbi), dim3(256), 0, h->st, h->scp_success, 0, B);
+    hipLaunchKernelGGL(k_fill_int, dim3(gbi), dim3(256), 0, h->st, h->scp_iters, 0, B);
+    if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, nullptr)) return -1;
+    for (int ii = 0; ii < max_it; ii++) {
         hipLaunchKernelGGL(k_cl_x0arg, dim3(64), dim3(256), 0, h->st, a);
-        if (slsqp_solve(h, h->x0arg, SLSQP_DEVICE, opts)) return -1;
+        if (solve_impl(h, h->x0arg, SLSQP_DEVICE, &o, h->scp_active)) return -1;
         tq += h->t_qp; ts += h->t_sweep; tt += h->t_total;
-        hipLaunchKernelGGL(k_cl_update, dim3(1024), dim3(256), 0, h->st, a);
+        HIPCHK(hipMemsetAsync(h->counter + 2, 0, sizeof(int), h->st));
+        ScpArgs sa{ii, converge ? 1 : 0, o.scp_eps, h->scp_active, h->scp_success, h->scp_iters, h->counter + 2, h->scp_dmax};
+        hipLaunchKernelGGL(k_cl_scp_update, dim3(B), dim3(64), 0, h->st, a, sa);
+        int nact = 0;
+        HIPCHK(hipMemcpyAsync(&nact, h->counter + 2, sizeof(int), hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+        if (nact == 0 || ii + 1 == max_it) break;
+        if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, h->scp_active)) return -1;   // update_jacobian for the next iteration (:138)
     }
     if (h->model_id == 0) hipLaunchKernelGGL((k_cl_shift_plant<0>), dim3(gb), dim3(64), 0, h->st, a, 0, 1);
     else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_shift_plant<1>), dim3(gb), dim3(64), 0, h->st, a, 0, 1);

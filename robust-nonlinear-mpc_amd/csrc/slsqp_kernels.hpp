@@ -741,12 +741,13 @@ __global__ __launch_bounds__(64) void k_ne_bwd_phase(QpArgs a) {
 // ------------------------------------------------------------------------------------------------
 // bounds of the un-tightened QP: QP.update_dynamics (qp_jit.py:268-273) + offset_constraints (:595-610)
 // ------------------------------------------------------------------------------------------------
-struct BoundsArgs { int B, N, NX, NI, NIF; const double *g, *gN, *c; double *ubg, *lbg; double eps; };
+struct BoundsArgs { int B, N, NX, NI, NIF; const double *g, *gN, *c; double *ubg, *lbg; double eps; const int *run; };
 __global__ void k_set_bounds(BoundsArgs a) {
     const int SR = a.NX + a.NI, mb = a.N * SR + a.NIF;
     const size_t tot = (size_t)a.B * mb;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
         const int b = idx / mb, r = idx % mb;
+        if (a.run && !a.run[b]) continue;
         double u, l;
         if (r < a.N * SR) {
             const int k = r / SR, i = r % SR;
@@ -1042,6 +1043,7 @@ struct LinArgs {
     const double *X, *U, *g_raw, *gf_raw;
     Costs cst;
     double *A, *Bm, *c, *g, *gN, *q;
+    const int *run;   // (B) 1 = linearise this instance (NULL = all)
 };
 template <int MODEL>
 __global__ void k_lin_jac(LinArgs a) {
@@ -1049,6 +1051,7 @@ __global__ void k_lin_jac(LinArgs a) {
     const size_t tot = (size_t)a.B * a.N * NZ;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
         const int dir = t % NZ, k = (t / NZ) % a.N, b = t / ((size_t)NZ * a.N);
+        if (a.run && !a.run[b]) continue;
         const double *x = a.X + ((size_t)b * (a.N + 1) + k) * NX, *u = a.U + ((size_t)b * a.N + k) * NU;
         double col[NX], f[NX];
         dyn::ddyn_jac_column<MODEL>(x, u, dir, col, dir == 0 ? f : nullptr);
@@ -1064,6 +1067,7 @@ __global__ void k_lin_vec(LinArgs a) {
     const size_t tot = (size_t)a.B * n;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
         const int e = t % n, b = t / n, k = e / NZ, i = e % NZ;
+        if (a.run && !a.run[b]) continue;
         const double z = (i < NX) ? a.X[((size_t)b * (a.N + 1) + k) * NX + i] : a.U[((size_t)b * a.N + k) * NU + (i - NX)];
         if (k < a.N) {
             double *g = a.g + ((size_t)b * a.N + k) * NI;
@@ -1092,16 +1096,38 @@ struct ClArgs {
     double *u0;                       // (B,NU) applied input
     const double *u_init;             // (NU) input used by the zero-order roll-out initialiser
 };
-// nominal += delta where the step succeeded (SCP_SLS_jit.py:426-430)
-__global__ void k_cl_update(ClArgs a) {
+// SCP bookkeeping of one socp_step for every instance still iterating (SCP_SLS.solve, solver/SCP_SLS_jit.py:113-135):
+//   step failed                      -> the instance leaves the loop, scp_success = 0                      (:118-119)
+//   step ok                          -> nominal += delta (:426-430); scp_iters = ii
+//   converge mode and |delta|inf < eps -> scp_success = 1, the instance leaves the loop BEFORE the next linearisation (:123-132)
+//   RTI mode                         -> scp_success = success of the last step                             (:148)
+// One wave per instance; n_active counts the instances that go on.
+struct ScpArgs { int ii, converge; double eps; int *active, *scp_success, *scp_iters, *n_active; double *dmax; };
+__global__ __launch_bounds__(64) void k_cl_scp_update(ClArgs a, ScpArgs s) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B || !s.active[b]) return;
     const int NZ = a.NX + a.NU, n = NZ * a.N + a.NX;
-    const size_t tot = (size_t)a.B * n;
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
-        const int e = t % n, b = t / n, k = e / NZ, i = e % NZ;
-        if (!a.success[b]) continue;
-        const double d = a.primal[t];
-        if (i < a.NX) a.Xn[((size_t)b * (a.N + 1) + k) * a.NX + i] += d;
-        else a.Un[((size_t)b * a.N + k) * a.NU + (i - a.NX)] += d;
+    if (!a.success[b]) {
+        if (lane == 0) { s.active[b] = 0; s.scp_success[b] = 0; s.scp_iters[b] = s.ii; }
+        return;
+    }
+    const double *d = a.primal + (size_t)b * n;
+    double dm = 0.0;
+    for (int e = lane; e < n; e += 64) {
+        const int k = e / NZ, i = e % NZ;
+        const double dv = d[e];
+        dm = fmax(dm, fabs(dv));
+        if (i < a.NX) a.Xn[((size_t)b * (a.N + 1) + k) * a.NX + i] += dv;
+        else a.Un[((size_t)b * a.N + k) * a.NU + (i - a.NX)] += dv;
+    }
+    dm = wla::wave_max(dm);
+    if (lane == 0) {
+        s.dmax[b] = dm;
+        s.scp_iters[b] = s.ii;
+        if (s.converge) {
+            if (dm < s.eps) { s.scp_success[b] = 1; s.active[b] = 0; }
+            else { s.scp_success[b] = 0; atomicAdd(s.n_active, 1); }
+        } else { s.scp_success[b] = 1; atomicAdd(s.n_active, 1); }
     }
 }
 __global__ void k_cl_x0arg(ClArgs a) {

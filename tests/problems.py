@@ -142,7 +142,7 @@ def host_jac(mid, x, u):
     return A, B, f
 
 
-def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=None):
+def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=None, scp_eps=1e-10, max_scp_iter=100):
     """Single-instance CPU closed loop: SCP_SLS.solve (solver/SCP_SLS_jit.py:65-152) with the zero-order roll-out initialiser,
     reset_warm_start (:500-551) and the plant update of the closed-loop scripts."""
     from oracle import oracle as O
@@ -157,14 +157,18 @@ def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=Non
         X[k + 1] = host_ddyn(mid, X[k], U[k])
     Hd = np.concatenate([np.concatenate([np.diag(m.Q), np.diag(m.R)])] * N + [np.diag(m.Qf)])
     xm = np.asarray(x0, dtype=float).copy()
-    log = dict(state=[], u0=[], nominal_x=[], nominal_u=[], backoff_x=[], success=[])
+    log = dict(state=[], u0=[], nominal_x=[], nominal_u=[], backoff_x=[], success=[], scp_iterations=[])
+    converge = rti is None or rti <= 0          # SCP_SLS default rti = -1: until |delta|inf < epsilon_convergence (SCP_SLS_jit.py:113-135)
     for i in range(steps):
         if i > 0:
             xN = host_ddyn(mid, X[N], U[N - 1])
             X[:N] = X[1:N + 1].copy(); U[:N - 1] = U[1:N].copy(); X[N] = xN
             fs.reset_solver_to_zeros()
         ok = True
-        for _ in range(rti):
+        converged = False
+        it_used = 0
+        for ii in range(max_scp_iter if converge else rti):
+            it_used = ii
             A = np.zeros((N, m.nx, m.nx)); Bm = np.zeros((N, m.nx, m.nu)); c = np.zeros((N, m.nx))
             for k in range(N):
                 A[k], Bm[k], f = host_jac(mid, X[k], U[k])
@@ -179,6 +183,12 @@ def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=Non
                 break
             X = X + sol["primal_x"].T
             U = U + sol["primal_u"].T
+            if converge and np.max(np.abs(sol["primal_vec"])) < scp_eps:
+                converged = True
+                break
+        if converge:
+            ok = ok and converged
+        log["scp_iterations"].append(it_used)
         log["state"].append(X[0].copy()); log["u0"].append(U[0].copy()); log["nominal_x"].append(X.copy()); log["nominal_u"].append(U.copy())
         log["backoff_x"].append(np.array(sol["backoff_x"]) if ok else None); log["success"].append(ok)
         xm = host_ddyn(mid, xm, U[0]) + (m.E @ W[i] if W is not None else 0.0)

@@ -212,6 +212,33 @@ def test_closed_loop_vs_oracle(model, N, steps, amp):
                 assert np.allclose(out["backoff_trajectory_x"][b][:, :, i].T, ref["backoff_x"][i], rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("model,N,steps,sls_steps", [("pendulum", 10, 2, None), ("pendulum", 10, 2, 2), ("quadrotor", 20, 1, 1)])
+def test_closed_loop_scp_converge_mode_vs_oracle(model, N, steps, sls_steps):
+    """SCP_SLS's default rti = -1 (BASELINE config 4, "full SCP_SLS_jit outer loop"): every instance iterates linearise -> fast-SLS ->
+    nominal += delta until |delta|inf < epsilon_convergence, leaving the loop on its own (SCP_SLS_jit.py:113-135); inner fast-SLS in
+    converge mode (sls_steps None, MAX_ITER 30) or RTI.  epsilon_convergence is loosened from the reference's 1e-10 to 1e-8 on BOTH
+    sides: the last digits of a QP solution are solver noise, and the test compares iteration counts."""
+    from robust_nonlinear_mpc_amd import ClosedLoopMPC, get_model
+    from problems import run_oracle_closed_loop
+    m = get_model(model)
+    B = 3
+    rng = np.random.default_rng(23)
+    x0 = np.stack([m.x_ref + 0.04 * (m.x_ub - m.x_lb) * rng.uniform(-1, 1, m.nx) for _ in range(B)])
+    cl = ClosedLoopMPC(m, N, B, rti=-1, fast_sls_rti_steps=sls_steps)
+    cl.f.opts.scp_eps = 1e-8
+    out = cl.run(x0, steps, None)
+    cl.close()
+    for b in range(B):
+        ref = run_oracle_closed_loop(m, N, x0[b], steps, -1, sls_steps, None, scp_eps=1e-8)
+        assert list(out["success"][b]) == list(ref["success"])
+        assert list(out["scp_iterations"][b]) == list(ref["scp_iterations"])
+        scale = max(1.0, np.abs(ref["nominal_x"]).max())
+        assert np.max(np.abs(out["nominal_trajectory_x"][b].transpose(2, 1, 0) - ref["nominal_x"])) < 1e-6 * scale
+        assert np.max(np.abs(out["nominal_trajectory_u"][b].transpose(2, 1, 0) - ref["nominal_u"])) < 1e-6 * max(1.0, np.abs(ref["nominal_u"]).max())
+    assert out["scp_iterations"].max() >= 2          # the loop really iterated
+    assert len({tuple(r) for r in out["scp_iterations"]}) >= 1
+
+
 def test_monte_carlo_seeds_and_npz_keys(tmp_path):
     """Seeded closed-loop Monte-Carlo (config 5 shape, tiny): distinct seeds give distinct trajectories, seed streams are
     reproducible run to run, and the npz written for one instance carries the reference's key set (main_rocket...:189-206)."""

@@ -4,8 +4,9 @@ reference's expe/main_rocket_robust_closed_loop.py `generate()` (same weights, E
 
     python examples/rocket_closed_loop.py --seeds 64 --steps 30 [--N 15] [--out results/]
 
-The reference starts from an IPOPT nominal trajectory; here the first nominal is a roll-out of the plant from x0 under zero input
-deviation (hover), so the first MPC steps differ from the reference's while the SCP iterations pull the nominal in.
+The reference starts from an IPOPT nominal trajectory (SCP_SLS.solve_nominal_trajectory); here `--init sqp` (default) solves the same
+nominal NLP on the GPU (slsqp_nominal_solve, trust-region SCP from a hover roll-out) and `--init rollout` uses the bare roll-out.
+`--x0-scale s` starts from x_ref + s (x0_script - x_ref).
 """
 import argparse
 import os
@@ -24,14 +25,18 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--N", type=int, default=15)          # the script's default horizon (main_rocket...:63)
     ap.add_argument("--x0-scale", type=float, default=1.0)
+    ap.add_argument("--init", default="sqp", choices=["sqp", "rollout"])
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     m = get_model("rocket")
     x0 = m.x_ref + a.x0_scale * (m.extra["x0"] - m.x_ref)
     t0 = time.perf_counter()
-    r = run_monte_carlo(m, a.N, np.arange(a.seeds), a.steps, x0)
+    r = run_monte_carlo(m, a.N, np.arange(a.seeds), a.steps, x0, solve_nominal=(a.init == "sqp"))
     dt = time.perf_counter() - t0
     ok = r["success"]
+    if "nlp_status" in r:
+        print(f"nominal NLP: status counts {np.bincount(r['nlp_status'], minlength=3).tolist()} (0 KKT point, 1 max QPs, 2 failed); "
+              f"accepted steps mean {r['nlp_iterations'].mean():.1f}")
     print(f"{a.seeds} seeds x {a.steps} MPC steps (N={a.N}) in {dt:.2f} s; solved steps: {ok.mean():.3f}; "
           f"final |pos| mean {np.linalg.norm(r['state_trajectory'][:, :3, -1], axis=1).mean():.3f} "
           f"(start {np.linalg.norm(x0[:3]):.3f}); QP {r['t_qp'].sum():.1f} ms, Riccati sweeps {r['t_riccati'].sum():.1f} ms")

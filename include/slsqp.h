@@ -125,6 +125,18 @@ int slsqp_linearize(slsqp_handle *h, const double *X, const double *U, int loc);
 int slsqp_cl_init(slsqp_handle *h, const double *x_meas, const double *X_nom, const double *U_nom, const double *u_init, int loc);
 int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc, const slsqp_opts *opts);
 
+/* ---- nominal-trajectory initialiser: replaces the reference's IPOPT call for the first MPC step
+   (SCP_SLS.solve_nominal_trajectory solver/SCP_SLS_jit.py:161-188, NLP of solver/nlp.py:158-217:
+   min sum x'Qx + u'Ru + xN'Qf xN  s.t. x+ = ddyn(x,u), G[x;u] <= g, Gf xN <= gf, x0 = x_meas).
+   Improves the nominal held by the handle (slsqp_cl_init: the caller's guess or the roll-out) for every instance by trust-region
+   sequential convex programming on the path's own QP kernel, until the step is below tol (default 1e-7) with feasible dynamics and
+   box, at most max_qp QP solves (default 120); rho (default 1e3) weighs constraint violation in the merit function.
+   Results via slsqp_get: nominal_x, nominal_u, nlp_status[int32] (0 converged to a KKT point, 1 max_qp reached, 2 failed:
+   no acceptable step / QP infeasible), nlp_iterations[int32] (accepted steps), nlp_info (12): w, kappa, kappa0, cost, defect l1, box
+   violation l1, last ratio, last |step|inf.  IPOPT output is not available offline: parity for this entry point is "unpinned";
+   tests certify the NLP's KKT conditions independently. */
+int slsqp_nominal_solve(slsqp_handle *h, int max_qp, double tol, double rho, const slsqp_opts *opts);
+
 /* ---- QP-level boundary: mirrors the three calls of the reference's generated module ----------------------- */
 /* P_x (B,nnzP): CSC data of triu(2P) (diagonal => nnzP = n);  A_x (B,nnzA): CSC data of the (m x n) constraint
    matrix INCLUDING the x0-pin rows, sorted indices, pattern of qp_jit.py:77-192 with G=[I;-I]. */

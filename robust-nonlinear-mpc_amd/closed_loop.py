@@ -37,9 +37,10 @@ class ClosedLoopMPC:
     def close(self):
         self.f.close()
 
-    def reset(self, x_meas, X_nom=None, U_nom=None, u_init=None):
+    def reset(self, x_meas, X_nom=None, U_nom=None, u_init=None, solve_nominal=False, max_qp=120, tol=1e-7, rho=1e3):
         """x_meas (B,nx).  X_nom (B,N+1,nx), U_nom (B,N,nu) optional initial nominal; else roll-out under `u_init` (default: the
-        model's neutral input)."""
+        model's neutral input).  solve_nominal=True then solves the nominal NLP from that guess on the GPU (the role IPOPT has in
+        SCP_SLS.solve_nominal_trajectory, SCP_SLS_jit.py:161-188); per-instance outcome in self.nlp_status (0 = KKT point found)."""
         f, m = self.f, self.m
         x_meas = _c(x_meas)
         assert x_meas.shape == (self.B, m.nx)
@@ -48,6 +49,12 @@ class ClosedLoopMPC:
         ui = _c(m.u_ref if u_init is None else u_init)
         L.check(f.lib.slsqp_cl_init(f.h, _ptr(x_meas), _ptr(Xn), _ptr(Un), _ptr(ui), L.HOST))
         self.steps_done = 0
+        self.nlp_status = None
+        if solve_nominal:
+            L.check(f.lib.slsqp_nominal_solve(f.h, int(max_qp), float(tol), float(rho), C.byref(f.opts)))
+            self.nlp_status = f.get("nlp_status", (), np.int32)
+            self.nlp_iterations = f.get("nlp_iterations", (), np.int32)
+            self.nlp_info = f.get("nlp_info", (12,))
 
     def step(self, w=None, fetch=True):
         """One MPC step of the whole batch.  w (B,nx): disturbance sample in [-1,1]^nx (x+ = ddyn(x,u0) + E w), or None."""
@@ -67,11 +74,11 @@ class ClosedLoopMPC:
             t_qp_ms=f.timing_ms()["qp"], t_riccati_ms=f.timing_ms()["sweep"],
         )
 
-    def run(self, x0, steps, W=None, X_nom=None, U_nom=None):
+    def run(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False):
         """Closed loop of `steps` MPC steps from x0 (B,nx); W (steps,B,nx) disturbance samples or None.  Returns arrays laid out
         like the reference's npz (expe/main_rocket_robust_closed_loop.py:189-206) with a leading batch axis."""
         m, N, B = self.m, self.N, self.B
-        self.reset(x0, X_nom, U_nom)
+        self.reset(x0, X_nom, U_nom, solve_nominal=solve_nominal)
         out = dict(
             state_trajectory=np.zeros((B, m.nx, steps)), input_trajectory=np.zeros((B, m.nu, max(steps - 1, 0))),
             nominal_trajectory_x=np.zeros((B, m.nx, N + 1, steps)), nominal_trajectory_u=np.zeros((B, m.nu, N, steps)),

@@ -48,6 +48,7 @@ struct slsqp_handle {
     double *eta, *eta_f, *beta, *beta_f, *backoff, *backoff_f, *backoff_x, *backoff_u, *K;
     int *status, *iters, *itnum, *has_prev, *conv, *alive, *mask, *success, *infeas, *counter;
     int *scp_active, *scp_success, *scp_iters, *pending_reset; double *scp_dmax;
+    double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
     // qp-level CSC maps
     int *mapA, *mapB;  // CSC offsets of A_k[i][j] / B_k[i][j]
     double *stage;     // staging buffer for host<->device transfers
@@ -63,7 +64,7 @@ struct slsqp_handle {
 static Costs costs_of(slsqp_handle *h) {
     const int nx = h->d.nx, nu = h->d.nu;
     Costs c;
-    c.Qd = h->cst; c.Rd = c.Qd + nx; c.Qfd = c.Rd + nu; c.Qregd = c.Qfd + nx; c.Rregd = c.Qregd + nx; c.Qregfd = c.Rregd + nu;
+    c.Qd = h->cst; c.Rd = c.Qd + nx; c.Qfd = c.Rd + nu; c.Qregd = c.Qfd + nx; c.Rregd = c.Qregd + nx; c.Qregfd = c.Rregd + nu; c.prox = 0.0;
     return c;
 }
 
@@ -114,6 +115,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->status, B); rc |= dalloc(&h->iters, B); rc |= dalloc(&h->itnum, B); rc |= dalloc(&h->has_prev, B); rc |= dalloc(&h->conv, B);
     rc |= dalloc(&h->alive, B); rc |= dalloc(&h->mask, B); rc |= dalloc(&h->success, B); rc |= dalloc(&h->infeas, B); rc |= dalloc(&h->counter, (size_t)4);
     rc |= dalloc(&h->scp_active, B); rc |= dalloc(&h->scp_success, B); rc |= dalloc(&h->scp_iters, B); rc |= dalloc(&h->pending_reset, B); rc |= dalloc(&h->scp_dmax, B);
+    rc |= dalloc(&h->nom_st, B * 12); rc |= dalloc(&h->nom_need_lin, B); rc |= dalloc(&h->nom_status, B); rc |= dalloc(&h->nom_iters, B);
     rc |= dalloc(&h->mapA, (size_t)N * nx * nx); rc |= dalloc(&h->mapB, (size_t)N * nx * nu);
     if (rc) { delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
@@ -147,6 +149,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     reg("status", h->status, sizeof(int)); reg("qp_iters", h->iters, sizeof(int)); reg("iteration_number", h->itnum, sizeof(int));
     reg("success", h->success, sizeof(int)); reg("scp_success", h->scp_success, sizeof(int)); reg("scp_iterations", h->scp_iters, sizeof(int));
     reg("scp_delta_max", h->scp_dmax, sizeof(double));
+    reg("nlp_status", h->nom_status, sizeof(int)); reg("nlp_iterations", h->nom_iters, sizeof(int)); reg("nlp_info", h->nom_st, sizeof(double) * 12);
     reg("beta", h->beta, sizeof(double) * N * N * ni); reg("beta_f", h->beta_f, sizeof(double) * (N + 1) * nif);
     reg("backoff", h->backoff, sizeof(double) * N * ni); reg("backoff_f", h->backoff_f, sizeof(double) * nif);
     reg("backoff_x", h->backoff_x, sizeof(double) * (N + 1) * nx); reg("backoff_u", h->backoff_u, sizeof(double) * N * nu);
@@ -166,7 +169,8 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->g_raw, h->Xn, h->Un, h->xmeas, h->x0arg, h->u0, h->wbuf, h->u_init, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
                     h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->ws, h->qpstate, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
                     h->backoff_u, h->K, h->status, h->iters, h->itnum, h->has_prev, h->conv, h->alive, h->mask, h->success, h->infeas,
-                    h->counter, h->mapA, h->mapB, h->scp_active, h->scp_success, h->scp_iters, h->pending_reset, h->scp_dmax};
+                    h->counter, h->mapA, h->mapB, h->scp_active, h->scp_success, h->scp_iters, h->pending_reset, h->scp_dmax,
+                    h->nom_st, h->nom_need_lin, h->nom_status, h->nom_iters};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : h->ev) hipEventDestroy(e);
     for (auto &e : h->kev) hipEventDestroy(e);
@@ -334,8 +338,9 @@ static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter) {
     return 0;
 }
 
-static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm) {
+static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr) {
     QpArgs a;
+    a.prox = prox; a.prox_stride = 12;
     a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;
     a.cst = costs_of(h); a.Linv = h->Linv; a.ws = h->ws; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
     a.status = h->status; a.iters = h->iters; a.max_iter = o->qp_max_iter; a.eps = o->qp_eps;
@@ -546,6 +551,55 @@ extern "C" int slsqp_cl_init(slsqp_handle *h, const double *x_meas, const double
     HIPCHK(hipMemsetAsync(h->has_prev, 0, sizeof(int) * B, h->st));   // a fresh SCP_SLS object has no convergence history
     HIPCHK(hipStreamSynchronize(h->st));
     return slsqp_reset(h);
+}
+
+// Nominal-trajectory initialiser: trust-region SCP on the path's QP kernel (see k_nom_eval).  Works on the nominal held by the
+// handle (slsqp_cl_init: caller's guess or roll-out) and the measured state given there.
+extern "C" int slsqp_nominal_solve(slsqp_handle *h, int max_qp, double tol, double rho, const slsqp_opts *opts) {
+    hipSetDevice(h->dev);
+    if (h->model_id < 0 || !h->have_costs || !h->have_cons) return fail("set_model, set_costs and set_constraints must be called first");
+    slsqp_opts o;
+    if (opts) o = *opts; else slsqp_default_opts(&o);
+    const slsqp_dims &d = h->d;
+    const int B = h->B, gbi = (B + 255) / 256;
+    if (max_qp <= 0) max_qp = 120;
+    if (!(tol > 0.0)) tol = 1e-7;
+    if (!(rho > 0.0)) rho = 1e3;
+    int *active = h->scp_active;
+    hipLaunchKernelGGL(k_nom_init, dim3(gbi), dim3(256), 0, h->st, B, h->nom_st, active, h->nom_need_lin, h->nom_status, h->nom_iters, 1.0, 0.5);
+    ClArgs ca = cl_args(h, nullptr);
+    NomArgs na;
+    na.B = B; na.N = d.N; na.Xn = h->Xn; na.Un = h->Un; na.primal = h->primal; na.qp_status = h->status; na.g_raw = h->g_raw; na.gf_raw = h->gf_raw;
+    na.cst = costs_of(h); na.st = h->nom_st; na.active = active; na.need_lin = h->nom_need_lin; na.status = h->nom_status; na.iters = h->nom_iters;
+    na.n_active = h->counter + 2; na.rho = rho; na.tol = tol; na.w_max = 1e8;
+    auto eval = [&](int mode) {
+        na.mode = mode;
+        if (h->model_id == 0) hipLaunchKernelGGL((k_nom_eval<0>), dim3(B), dim3(128), 0, h->st, na);
+        else if (h->model_id == 1) hipLaunchKernelGGL((k_nom_eval<1>), dim3(B), dim3(128), 0, h->st, na);
+        else hipLaunchKernelGGL((k_nom_eval<2>), dim3(B), dim3(128), 0, h->st, na);
+    };
+    eval(0);
+    double tq = 0;
+    for (int it = 0; it < max_qp; it++) {
+        if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, h->nom_need_lin)) return -1;     // accepted instances only; the others re-solve
+        NomBoundsArgs ba{B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->nom_st, active, h->ubg, h->lbg, 1e-10};
+        hipLaunchKernelGGL(k_nom_bounds, dim3(1024), dim3(256), 0, h->st, ba);
+        hipLaunchKernelGGL(k_cl_x0arg, dim3(64), dim3(256), 0, h->st, ca);                   // x0arg = x_nom0 - x_meas
+        hipLaunchKernelGGL(k_negate, dim3((B * d.nx + 255) / 256), dim3(256), 0, h->st, h->x0arg, h->x0val, B * d.nx);
+        HIPCHK(hipEventRecord(h->ev[6], h->st));
+        if (launch_qp(h, active, &o, it > 0 ? 1 : 0, h->nom_st /* S[0] = w: stride 12 */)) return -1;
+        HIPCHK(hipEventRecord(h->ev[7], h->st));
+        HIPCHK(hipMemsetAsync(h->counter + 2, 0, sizeof(int), h->st));
+        eval(1);
+        int nact = 0;
+        HIPCHK(hipMemcpyAsync(&nact, h->counter + 2, sizeof(int), hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+        tq += ev_ms(h->ev[6], h->ev[7]);
+        if (nact == 0) break;
+    }
+    h->t_qp = tq; h->t_total = tq; h->t_sweep = 0;
+    h->have_dyn = false;   // the bounds in the handle are the initialiser's, not the path's: linearise again before slsqp_solve
+    return 0;
 }
 
 // One MPC step for the whole batch: [warm-start shift + solver reset] -> rti x (linearise, fast-SLS solve of x_nom0 - x_meas,

@@ -30,6 +30,7 @@ constexpr int ST_INIT = -1;
 struct Costs {  // batch-constant diagonal weights (device pointers)
     const double *Qd, *Rd, *Qfd;        // diag of Q, R, Qf (P = 2*blkdiag)
     const double *Qregd, *Rregd, *Qregfd;
+    double prox;                        // added to every diagonal entry of blkdiag(Q,R,..,Qf) (trust-region weight of the nominal initialiser; 0 on the path)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -69,6 +70,8 @@ struct QpArgs {
     double init_s, init_lam;  // starting slack floor / multiplier of the interior point
     int warm_rounds;          // active-set correction rounds allowed in a warm attempt before falling back
     int warm;                 // 1: try an active-set polish from the previous solution of each instance first
+    const double *prox;       // per-instance proximal weight added to the diagonal cost (element b * prox_stride), or NULL
+    int prox_stride;
 };
 
 // LDS layout of one QP wave: 5 rotating NX x NX buffers (A_k | Y_k | L_{k,k-1} (also B diag(pi_u)) | Linv_{k-1} | M1 -> Linv_k),
@@ -271,11 +274,11 @@ __device__ __forceinline__ Elem elem_of(int e, int n, int N, const double *ub, c
     const int k = e / NZ, i = e % NZ;
     r.q = qg[e];
     if (k < N) {
-        r.pd = 2.0 * (i < NX ? cst.Qd[i] : cst.Rd[i - NX]);
+        r.pd = 2.0 * ((i < NX ? cst.Qd[i] : cst.Rd[i - NX]) + cst.prox);
         r.hi = ub[k * SR + NX + i];
         r.lo = -ub[k * SR + NX + NZ + i];
     } else {
-        r.pd = 2.0 * cst.Qfd[i];
+        r.pd = 2.0 * (cst.Qfd[i] + cst.prox);
         r.hi = ub[N * SR + i];
         r.lo = -ub[N * SR + NX + i];
     }
@@ -359,7 +362,8 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
     double *ws = a.ws + (size_t)b * qp_ws_doubles(n, N, NX);
     double *Z = ws, *SU = Z + n, *SL = SU + n, *LU = SL + n, *LL = LU + n, *GC = LL + n, *CU = GC + n, *CL = CU + n;
     double *PI = CL + n, *V = PI + n, *G = V + n, *ACT = G + n, *W = ACT + n, *NUA = W + N * NX, *NUP = NUA + N * NX;
-    const Costs cst = a.cst;
+    Costs cst = a.cst;
+    cst.prox = a.prox ? a.prox[(size_t)b * a.prox_stride] : 0.0;
     QpState *stp = (QpState *)a.state + b;
 
     if (first) {
@@ -1182,6 +1186,151 @@ __global__ void k_cl_rollout(ClArgs a) {
         dyn::ddyn<MODEL, double>(x, u, xp);
         for (int i = 0; i < NX; i++) { x[i] = xp[i]; X[(size_t)(k + 1) * NX + i] = xp[i]; }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Nominal-trajectory initialiser.  The reference obtains the first nominal from IPOPT
+// (SCP_SLS.solve_nominal_trajectory solver/SCP_SLS_jit.py:161-188; NLP of solver/nlp.py:158-217):
+//     min sum_k x_k'Q x_k + u_k'R u_k + x_N'Qf x_N   s.t. x_{k+1} = ddyn(x_k,u_k), G[x_k;u_k] <= g, Gf x_N <= gf, x_0 = x_meas.
+// Here the same NLP is solved per instance by sequential convex programming on the path's own QP kernel:
+//   QP_j:  min (y+d)'H(y+d) + w d'd   s.t.  A dx + B du - dx+ = -tau c,   box relaxed to  hi + (1-tau) max(y-hi,0)  (same for lo)
+// i.e. a step removes the fraction tau of the current constraint violation (dynamics defect c and box violation), w is a
+// trust-region (proximal) weight.  Steps are judged by the ratio of actual to predicted decrease of the exact-penalty merit
+// f + rho (|defect|_1 + |box violation|_1); rejected steps raise w and lower tau, good steps do the opposite.  At w -> 0,
+// tau = 1 this is the plain SCP iteration of SCP_SLS without tightening, so its fixed points are KKT points of the NLP.
+// State per instance S[12]: [0] w [1] kappa = 1-tau of the QP just solved / to solve [2] kappa0 (next first try) [3] f0 [4] c0 [5] v0
+// [6] last ratio [7] last |d|inf.
+// ------------------------------------------------------------------------------------------------
+struct NomArgs {
+    int B, N;
+    double *Xn, *Un;
+    const double *primal;
+    const int *qp_status;
+    const double *g_raw, *gf_raw;
+    Costs cst;
+    double *st;
+    int *active, *need_lin, *status, *iters, *n_active;
+    double rho, tol, w_max;
+    int mode;   // 0: merit at the current nominal (start of the iteration); 1: judge the step of the QP just solved
+};
+__device__ __forceinline__ double block_sum128(double v, double *red) {
+    const int t = threadIdx.x;
+    red[t] = v; __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+    const double r = red[0]; __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_max128(double v, double *red) {
+    const int t = threadIdx.x;
+    red[t] = v; __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) { if (t < s) red[t] = fmax(red[t], red[t + s]); __syncthreads(); }
+    const double r = red[0]; __syncthreads();
+    return r;
+}
+template <int MODEL>
+__global__ __launch_bounds__(128) void k_nom_eval(NomArgs a) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU, NZ = NX + NU;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (!a.active[b]) return;
+    __shared__ double red[128];
+    __shared__ int dec_s;
+    const int N = a.N, n = NZ * N + NX;
+    double *X = a.Xn + (size_t)b * (N + 1) * NX, *U = a.Un + (size_t)b * N * NU;
+    const double *d = a.primal + (size_t)b * n;
+    double *S = a.st + (size_t)b * 12;
+    const bool trial = a.mode == 1;
+    double f = 0.0, v = 0.0, dm = 0.0, c = 0.0;
+    for (int e = t; e < n; e += 128) {
+        const int k = e / NZ, i = e % NZ;
+        const double z0 = (i < NX) ? X[k * NX + i] : U[k * NU + (i - NX)];
+        const double dv = trial ? d[e] : 0.0, z = z0 + dv;
+        const double hw = (k < N) ? (i < NX ? a.cst.Qd[i] : a.cst.Rd[i - NX]) : a.cst.Qfd[i];
+        const double hi = (k < N) ? a.g_raw[i] : a.gf_raw[i], lo = (k < N) ? -a.g_raw[NZ + i] : -a.gf_raw[NX + i];
+        f += hw * z * z;
+        if (e >= NX) v += fmax(z - hi, 0.0) + fmax(lo - z, 0.0);   // x_0 is data (pinned to x_meas), its box is not the solver's to fix
+        dm = fmax(dm, fabs(dv));
+    }
+    for (int k = t; k < N; k += 128) {
+        double x[NX], u[NU], xp[NX];
+        for (int i = 0; i < NX; i++) x[i] = X[k * NX + i] + (trial ? d[k * NZ + i] : 0.0);
+        for (int i = 0; i < NU; i++) u[i] = U[k * NU + i] + (trial ? d[k * NZ + NX + i] : 0.0);
+        dyn::ddyn<MODEL, double>(x, u, xp);
+        for (int i = 0; i < NX; i++) c += fabs(xp[i] - (X[(k + 1) * NX + i] + (trial ? d[(k + 1) * NZ + i] : 0.0)));
+    }
+    f = block_sum128(f, red); v = block_sum128(v, red); c = block_sum128(c, red); dm = block_max128(dm, red);
+    if (t == 0) {
+        int dec = 0;   // 0 retry the QP (same linearisation), 1 step accepted, 2 converged, 3 failed
+        double w = S[0], kap = S[1], kap0 = S[2];
+        const double f0 = S[3], c0 = S[4], v0 = S[5];
+        if (!trial) {
+            S[3] = f; S[4] = c; S[5] = v; S[1] = (v > 1e-9 || c > 1e-6) ? kap0 : 0.0;
+            dec = -1;
+        } else {
+            const int qs = a.qp_status[b];
+            const double phi0 = f0 + a.rho * (c0 + v0);
+            double r = 0.0;
+            if (!(qs == 0 || qs == 4)) {       // QP infeasible at this tau: ask for less
+                if (kap < 0.995) { kap = 1.0 - 0.3 * (1.0 - kap); dec = 0; } else dec = 3;
+            } else {
+                const double pred = phi0 - (f + a.rho * kap * (v0 + c0));     // linearised model: violation shrinks to kappa * (v0 + c0)
+                const double act = phi0 - (f + a.rho * (c + v));
+                r = pred > 0.0 ? act / pred : -1.0;
+                if (pred <= 1e-12 * fmax(1.0, fabs(phi0)) || dm < a.tol) dec = (v0 < 1e-9 && c0 < 1e-7) ? 2 : 1;
+                else if (r < 0.1) { w *= 4.0; kap = 1.0 - (1.0 - kap) / 3.0; dec = (w > a.w_max) ? 3 : 0; }
+                else { dec = 1; kap0 = kap; if (r > 0.7) { w = fmax(w / 3.0, 1e-6); kap0 = kap > 0.01 ? kap / 3.0 : 0.0; } }
+            }
+            S[6] = r; S[7] = dm;
+            if (dec == 1 || dec == 2) {
+                S[3] = f; S[4] = c; S[5] = v;
+                kap = (v > 1e-9 || c > 1e-6) ? kap0 : 0.0;
+                a.iters[b] += 1;
+            }
+            S[0] = w; S[1] = kap; S[2] = kap0;
+            a.need_lin[b] = (dec == 1) ? 1 : 0;
+            if (dec == 2) { a.status[b] = 0; a.active[b] = 0; }
+            else if (dec == 3) { a.status[b] = 2; a.active[b] = 0; }
+            else atomicAdd(a.n_active, 1);
+        }
+        dec_s = dec;
+    }
+    __syncthreads();
+    if (dec_s == 1 || dec_s == 2) {
+        for (int e = t; e < n; e += 128) {
+            const int k = e / NZ, i = e % NZ;
+            if (i < NX) X[k * NX + i] += d[e]; else U[k * NU + (i - NX)] += d[e];
+        }
+    }
+}
+// bounds of the initialiser's QP: dynamics rows -tau c (+-eps), box rows g_k + kappa max(-g_k, 0) (g_k = g - G y, so max(-g_k,0) is the
+// current violation); the box of x_0 is dropped (x_0 is pinned).
+struct NomBoundsArgs { int B, N, NX, NI, NIF; const double *g, *gN, *c, *st; const int *run; double *ubg, *lbg; double eps; };
+__global__ void k_nom_bounds(NomBoundsArgs a) {
+    const int SR = a.NX + a.NI, mb = a.N * SR + a.NIF, NZ = a.NI / 2;
+    const size_t tot = (size_t)a.B * mb;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = idx / mb, r = idx % mb;
+        if (a.run && !a.run[b]) continue;
+        const double kap = a.st[(size_t)b * 12 + 1];
+        double u, l;
+        if (r < a.N * SR) {
+            const int k = r / SR, i = r % SR;
+            if (i < a.NX) { const double cv = (1.0 - kap) * a.c[((size_t)b * a.N + k) * a.NX + i]; u = -cv + a.eps; l = -cv - a.eps; }
+            else {
+                const int j = i - a.NX;
+                const double gv = a.g[((size_t)b * a.N + k) * a.NI + j];
+                u = (k == 0 && (j % NZ) < a.NX) ? 1e20 : gv + kap * fmax(-gv, 0.0) + a.eps; l = -1e20;
+            }
+        } else { const double gv = a.gN[(size_t)b * a.NIF + (r - a.N * SR)]; u = gv + kap * fmax(-gv, 0.0) + a.eps; l = -1e20; }
+        a.ubg[idx] = u; a.lbg[idx] = l;
+    }
+}
+__global__ void k_nom_init(int B, double *st, int *active, int *need_lin, int *status, int *iters, double w0, double kappa0) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double *S = st + (size_t)b * 12;
+    for (int i = 0; i < 12; i++) S[i] = 0.0;
+    S[0] = w0; S[1] = kappa0; S[2] = kappa0;
+    active[b] = 1; need_lin[b] = 1; status[b] = 1; iters[b] = 0;
 }
 
 }  // namespace slsqp

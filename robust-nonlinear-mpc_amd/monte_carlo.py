@@ -15,7 +15,7 @@ def disturbance_stream(seed, steps, nx):
     return np.stack([2.0 * rs.rand(nx) - 1.0 for _ in range(steps)])
 
 
-def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise=True, gather=True):
+def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise=True, gather=True, solve_nominal=False):
     seeds = np.asarray(seeds)
     S = len(seeds)
     lo, hi = shard_range(S, rank, world)
@@ -23,9 +23,12 @@ def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise
     B = len(mine)
     W = np.stack([disturbance_stream(s, steps, model.nx) for s in mine], axis=1) if noise else None   # (steps, B, nx)
     cl = ClosedLoopMPC(model, N, B, device=device)
-    out = cl.run(np.tile(np.asarray(x0, dtype=float), (B, 1)), steps, W)
+    out = cl.run(np.tile(np.asarray(x0, dtype=float), (B, 1)), steps, W, solve_nominal=solve_nominal)
+    nlp = None if cl.nlp_status is None else dict(nlp_status=cl.nlp_status, nlp_iterations=cl.nlp_iterations)
     cl.close()
     res = dict(seeds=mine, **out)
+    if nlp:
+        res.update(nlp)
     if gather and world > 1:
         import torch
         dev = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")

@@ -239,6 +239,75 @@ def test_closed_loop_scp_converge_mode_vs_oracle(model, N, steps, sls_steps):
     assert len({tuple(r) for r in out["scp_iterations"]}) >= 1
 
 
+def _nlp_kkt_residual(m, N, X, U, x_meas):
+    """Independent certificate for the nominal NLP (solver/nlp.py:158-217): dynamics defect, box violation, and the stationarity
+    residual min over multipliers (nu free, lambda >= 0 on active bounds only) of |2 H y + J' nu + sum_active +-lambda|."""
+    from scipy.optimize import lsq_linear
+    from problems import host_ddyn, host_jac
+    nx, nu, nz, mid = m.nx, m.nu, m.nz, m.model_id
+    n = nz * N + nx
+    y = np.concatenate([np.concatenate([X[k], U[k]]) for k in range(N)] + [X[N]])
+    Hd = np.concatenate([np.concatenate([np.diag(m.Q), np.diag(m.R)])] * N + [np.diag(m.Qf)])
+    hi = np.concatenate([np.concatenate([m.x_ub, m.u_ub])] * N + [m.x_ub])
+    lo = np.concatenate([np.concatenate([m.x_lb, m.u_lb])] * N + [m.x_lb])
+    J = np.zeros((nx * (N + 1), n))
+    J[:nx, :nx] = np.eye(nx)
+    defect = 0.0
+    for k in range(N):
+        A, Bm, f = host_jac(mid, X[k], U[k])
+        r = nx * (k + 1)
+        J[r:r + nx, k * nz:k * nz + nx] = A
+        J[r:r + nx, k * nz + nx:(k + 1) * nz] = Bm
+        J[r:r + nx, (k + 1) * nz:(k + 1) * nz + nx] = -np.eye(nx)
+        defect = max(defect, np.abs(f - X[k + 1]).max())
+    viol = max(np.maximum(y[nx:] - hi[nx:], 0).max(), np.maximum(lo[nx:] - y[nx:], 0).max())
+    act_u = np.where((np.abs(y - hi) < 1e-7) & (np.arange(n) >= nx))[0]
+    act_l = np.where((np.abs(y - lo) < 1e-7) & (np.arange(n) >= nx))[0]
+    cols = [J.T] + [np.eye(n)[:, act_u], -np.eye(n)[:, act_l]]
+    M = np.hstack(cols)
+    lb = np.concatenate([-np.inf * np.ones(J.shape[0]), np.zeros(len(act_u) + len(act_l))])
+    sol = lsq_linear(M, -2.0 * Hd * y, bounds=(lb, np.inf * np.ones(M.shape[1])), tol=1e-14, max_iter=500)
+    stat = np.abs(M @ sol.x + 2.0 * Hd * y).max() / max(1.0, np.abs(2.0 * Hd * y).max())
+    return defect, viol, stat, np.abs(X[0] - x_meas).max(), len(act_u) + len(act_l)
+
+
+@pytest.mark.parametrize("model,N,amp", [("pendulum", 10, 0.2), ("quadrotor", 20, 0.15), ("rocket", 20, 0.2)])
+def test_nominal_initialiser_reaches_nlp_kkt_point(model, N, amp):
+    """slsqp_nominal_solve (the role of IPOPT in SCP_SLS.solve_nominal_trajectory, SCP_SLS_jit.py:161-188) from the zero-order roll-out:
+    every instance must end at a point that satisfies the nominal NLP's KKT conditions, certified here independently of the solver
+    (CPU dynamics/Jacobians + a bounded least-squares fit of the multipliers).  No IPOPT output exists offline: parity unpinned."""
+    from robust_nonlinear_mpc_amd import ClosedLoopMPC, get_model
+    m = get_model(model)
+    B = 6
+    x0 = []
+    for s in range(B):
+        rng = np.random.default_rng(100 + s)
+        x = m.x_ref + amp * 0.25 * (m.x_ub - m.x_lb) * rng.uniform(-1, 1, m.nx)
+        if model != "pendulum":
+            x[6:10] /= np.linalg.norm(x[6:10])
+        x0.append(x)
+    x0 = np.stack(x0)
+    if model == "pendulum":
+        x0[0] = m.extra["x0"]
+    cl = ClosedLoopMPC(m, N, B)
+    cl.reset(x0, solve_nominal=True)
+    X, U = cl.f.get("nominal_x", (N + 1, m.nx)), cl.f.get("nominal_u", (N, m.nu))
+    st, its, info = cl.nlp_status, cl.nlp_iterations, cl.nlp_info
+    # the roll-out itself is far from optimal / feasible for at least one instance, so the solver had work to do
+    assert its.max() >= 3
+    assert (st == 0).all(), (st, its, info[:, :8])
+    nact = 0
+    for b in range(B):
+        defect, viol, stat, pin, na = _nlp_kkt_residual(m, N, X[b], U[b], x0[b])
+        assert defect < 1e-6 and viol < 1e-8 and pin < 1e-12, (b, defect, viol, pin)
+        assert stat < 1e-5, (b, stat)
+        nact += na
+    # and a closed-loop step from the solved nominal works
+    r = cl.step(None)
+    assert r["success"].all()
+    cl.close()
+
+
 def test_monte_carlo_seeds_and_npz_keys(tmp_path):
     """Seeded closed-loop Monte-Carlo (config 5 shape, tiny): distinct seeds give distinct trajectories, seed streams are
     reproducible run to run, and the npz written for one instance carries the reference's key set (main_rocket...:189-206)."""

@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--model", default="rocket")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--precision", type=int, default=0, help="0: fp64 (headline); 1: mixed fp32 factorisation / fp64 residuals (secondary figure)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
@@ -101,6 +102,7 @@ def main():
     f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=B, device=local_rank)
     f.set_rti_steps(m.fast_sls_rti_steps if args.model == "rocket" else 1)
     f.opts.warm_rounds = int(os.environ.get('QP_WARM_ROUNDS', '4'))
+    f.opts.precision = args.precision
     f.opts.warm_start = 0   # QP#1 of every step is solved cold (fresh Monte-Carlo instances); QP#2 warm-starts from QP#1
     dev = DeviceBatch(f, batch)
 
@@ -150,7 +152,7 @@ def main():
     out = {
         "metric": "QP solves/sec (whole node), rockETH N=20 batch=4096 RTI MPC step", "value": value, "unit": "QP solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 0 else "f32 factorisation + f64 residuals (mixed)", "data": "synthetic",
         "config": {"workload": f"{args.model} N={N} batch={B}/GPU, fast-SLS RTI step (rti_steps=1: 2 QP solves + 1 SLS sweep per instance)",
                    "qp_n": f.n, "qp_m": f.mb + m.nx, "solved_frac": float(np.mean((st == 0) | (st == 4))),
                    "polished_frac": float(np.mean(st == 0)), "ipm_iters_mean_last_qp": float(its.mean()), "ipm_iters_max_last_qp": int(its.max()),

@@ -67,6 +67,9 @@ typedef struct {
     int warm_rounds;     /* active-set correction rounds a warm attempt may use before falling back (default 4) */
     int max_scp_iter;    /* MAX_ITER_SCP (100, SCP_SLS_jit.py:47): cap of the SCP loop of slsqp_cl_step in converge mode (rti <= 0) */
     double scp_eps;      /* epsilon_convergence (1e-10, SCP_SLS_jit.py:29): SCP converged when |delta_vec|inf < scp_eps */
+    int precision;       /* 0 (default): fp64 throughout.  1: mixed -- block factorisations, stored inverses and substitutions in fp32,
+                            right-hand sides / residuals / KKT certificate in fp64, one more refinement solve per polish; instances
+                            that do not certify are solved again in fp64 (BASELINE config 3, "fp32 vs fp64") */
 } slsqp_opts;
 
 void slsqp_default_opts(slsqp_opts *o);
@@ -155,7 +158,7 @@ int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta_f, double 
    measured with HIP events on the handle's stream: [0] total, [1] QP kernel(s), [2] sweep kernel, [3] other */
 int slsqp_last_timing(slsqp_handle *h, double *ms4);
 /* accumulated since the last call: [0] total ms of k_ne_fwd launches (HIP events around each launch, handle's stream),
-   [1] number of launches; resets the accumulators */
+   [1] number of launches, [2] instances re-solved in fp64 after a mixed-precision attempt; resets the accumulators */
 int slsqp_kernel_timing(slsqp_handle *h, double *out3);
 void *slsqp_stream(slsqp_handle *h); /* hipStream_t, for callers that share device buffers */
 

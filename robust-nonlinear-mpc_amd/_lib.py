@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libslsqp_hip.so")
+SO_PATH = os.environ.get("SLSQP_SO") or os.path.join(_HERE, "csrc", "libslsqp_hip.so")   # SLSQP_SO: experiment builds only
 HOST, DEVICE = 0, 1
 
 
@@ -15,7 +15,7 @@ class Dims(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("rti_steps", C.c_int), ("max_sls_iter", C.c_int), ("qp_max_iter", C.c_int), ("qp_eps", C.c_double),
                 ("conv_tol", C.c_double), ("eps_backoff", C.c_double), ("want_K", C.c_int), ("warm_start", C.c_int), ("warm_rounds", C.c_int),
-                ("max_scp_iter", C.c_int), ("scp_eps", C.c_double)]
+                ("max_scp_iter", C.c_int), ("scp_eps", C.c_double), ("precision", C.c_int)]
 
 
 EXPORTS = [

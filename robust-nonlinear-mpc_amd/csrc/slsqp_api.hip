@@ -31,7 +31,7 @@ extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
     o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-6; o->conv_tol = 1e-3;
     o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 4;
-    o->max_scp_iter = 100; o->scp_eps = 1e-10;
+    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0;
 }
 
 struct slsqp_handle {
@@ -49,6 +49,7 @@ struct slsqp_handle {
     int *status, *iters, *itnum, *has_prev, *conv, *alive, *mask, *success, *infeas, *counter;
     int *scp_active, *scp_success, *scp_iters, *pending_reset; double *scp_dmax;
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
+    int *retry; int mx_retry, mx_retry_total;
     // qp-level CSC maps
     int *mapA, *mapB;  // CSC offsets of A_k[i][j] / B_k[i][j]
     double *stage;     // staging buffer for host<->device transfers
@@ -115,6 +116,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->status, B); rc |= dalloc(&h->iters, B); rc |= dalloc(&h->itnum, B); rc |= dalloc(&h->has_prev, B); rc |= dalloc(&h->conv, B);
     rc |= dalloc(&h->alive, B); rc |= dalloc(&h->mask, B); rc |= dalloc(&h->success, B); rc |= dalloc(&h->infeas, B); rc |= dalloc(&h->counter, (size_t)4);
     rc |= dalloc(&h->scp_active, B); rc |= dalloc(&h->scp_success, B); rc |= dalloc(&h->scp_iters, B); rc |= dalloc(&h->pending_reset, B); rc |= dalloc(&h->scp_dmax, B);
+    rc |= dalloc(&h->retry, B); h->mx_retry = 0; h->mx_retry_total = 0;
     rc |= dalloc(&h->nom_st, B * 12); rc |= dalloc(&h->nom_need_lin, B); rc |= dalloc(&h->nom_status, B); rc |= dalloc(&h->nom_iters, B);
     rc |= dalloc(&h->mapA, (size_t)N * nx * nx); rc |= dalloc(&h->mapB, (size_t)N * nx * nu);
     if (rc) { delete h; return nullptr; }
@@ -170,7 +172,7 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
                     h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->ws, h->qpstate, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
                     h->backoff_u, h->K, h->status, h->iters, h->itnum, h->has_prev, h->conv, h->alive, h->mask, h->success, h->infeas,
                     h->counter, h->mapA, h->mapB, h->scp_active, h->scp_success, h->scp_iters, h->pending_reset, h->scp_dmax,
-                    h->nom_st, h->nom_need_lin, h->nom_status, h->nom_iters};
+                    h->nom_st, h->nom_need_lin, h->nom_status, h->nom_iters, h->retry};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : h->ev) hipEventDestroy(e);
     for (auto &e : h->kev) hipEventDestroy(e);
@@ -311,23 +313,25 @@ __global__ void k_join_y(int B, int mb, int nx, const double *dual, const double
 
 // ---- kernel dispatch ---------------------------------------------------------------------------------------
 template <int NX, int NU>
-static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter) {
-    const size_t lds = sizeof(double) * qp_lds_doubles<NX, NU>(h->d.N);
+static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter, bool mx) {
+    const size_t lds = mx ? QpLdsMx<NX, NU>::BYTES : sizeof(double) * qp_lds_doubles<NX, NU>(h->d.N);
     const dim3 grid(h->B), blk(64);
     HIPCHK(hipMemsetAsync(a.n_active, 0, sizeof(int), h->st));
     hipLaunchKernelGGL((k_phase<NX, NU>), grid, blk, 0, h->st, a, 1);
-    // every instance needs 1 (start) + 2 per interior-point iteration + 3 per polish round ticks; poll the number of
+    // every instance needs 1 (start) + 2 per interior-point iteration + (1 + n_refine) per polish round ticks; poll the number of
     // unfinished instances every few ticks instead of running the worst case
-    const int max_ticks = 1 + 2 * max_iter + 3 + 2 * 10 + 8 + 2;
+    const int max_ticks = 1 + 2 * max_iter + 3 + 2 * 10 + 8 + 2 + 16;
     int tick = 0, active = 1;
     while (tick < max_ticks && active > 0) {
         const int burst = tick < 12 ? 12 : 3;
         for (int i = 0; i < burst; i++, tick++) {
             const bool timed = h->n_kev + 2 <= (int)h->kev.size();
             if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
-            hipLaunchKernelGGL((k_ne_fwd<NX, NU>), grid, blk, lds, h->st, a);
+            if (mx) hipLaunchKernelGGL((k_ne_fwd_mx<NX, NU>), grid, blk, lds, h->st, a);
+            else hipLaunchKernelGGL((k_ne_fwd<NX, NU>), grid, blk, lds, h->st, a);
             if (timed) { hipEventRecord(h->kev[h->n_kev + 1], h->st); h->n_kev += 2; }
-            hipLaunchKernelGGL((k_ne_bwd_phase<NX, NU>), grid, blk, lds, h->st, a);
+            if (mx) hipLaunchKernelGGL((k_ne_bwd_phase_mx<NX, NU>), grid, blk, lds, h->st, a);
+            else hipLaunchKernelGGL((k_ne_bwd_phase<NX, NU>), grid, blk, lds, h->st, a);
         }
         HIPCHK(hipMemcpyAsync(&active, a.n_active, sizeof(int), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
@@ -338,6 +342,15 @@ static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter) {
     return 0;
 }
 
+// instances of `run` whose mixed-precision solve did not end on the KKT certificate are solved again in fp64
+__global__ void k_mark_retry(int B, const int *run, const int *status, int *retry, int *count) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int r = (!run || run[b]) && status[b] != 0 && status[b] != 2;
+    retry[b] = r;
+    if (r) atomicAdd(count, 1);
+}
+
 static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr) {
     QpArgs a;
     a.prox = prox; a.prox_stride = 12;
@@ -346,9 +359,30 @@ static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int w
     a.status = h->status; a.iters = h->iters; a.max_iter = o->qp_max_iter; a.eps = o->qp_eps;
     a.state = h->qpstate; a.n_active = h->counter + 1; a.warm = warm; a.warm_rounds = o->warm_rounds;
     a.init_s = getenv("SLSQP_INIT_S") ? atof(getenv("SLSQP_INIT_S")) : 1.0; a.init_lam = getenv("SLSQP_INIT_LAM") ? atof(getenv("SLSQP_INIT_LAM")) : 0.0;
-    if (h->d.nx == 4) return launch_qp_t<4, 1>(h, a, o->qp_max_iter);
-    if (h->d.nx == 13) return launch_qp_t<13, 4>(h, a, o->qp_max_iter);
-    return launch_qp_t<17, 4>(h, a, o->qp_max_iter);
+    const bool mx = o->precision == 1;
+    a.n_refine = mx ? 3 : 2;
+    a.early_ctol = mx ? 1e-2 : 1e-6;
+    auto go = [&](const QpArgs &q, bool m) {
+        if (h->d.nx == 4) return launch_qp_t<4, 1>(h, q, o->qp_max_iter, m);
+        if (h->d.nx == 13) return launch_qp_t<13, 4>(h, q, o->qp_max_iter, m);
+        return launch_qp_t<17, 4>(h, q, o->qp_max_iter, m);
+    };
+    if (go(a, mx)) return -1;
+    h->mx_retry = 0;
+    if (mx) {
+        HIPCHK(hipMemsetAsync(h->counter + 3, 0, sizeof(int), h->st));
+        hipLaunchKernelGGL(k_mark_retry, dim3((h->B + 255) / 256), dim3(256), 0, h->st, h->B, run, h->status, h->retry, h->counter + 3);
+        int nretry = 0;
+        HIPCHK(hipMemcpyAsync(&nretry, h->counter + 3, sizeof(int), hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+        h->mx_retry = nretry; h->mx_retry_total += nretry;
+        if (nretry > 0) {
+            QpArgs r = a;
+            r.run = h->retry; r.warm = 0; r.n_refine = 2; r.early_ctol = 1e-6;
+            if (go(r, false)) return -1;
+        }
+    }
+    return 0;
 }
 
 template <int NX, int NU>
@@ -441,8 +475,8 @@ extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms4) {
     return 0;
 }
 extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out3) {
-    out3[0] = h->t_fwd; out3[1] = (double)h->n_fwd; out3[2] = 0.0;
-    h->t_fwd = 0; h->n_fwd = 0;
+    out3[0] = h->t_fwd; out3[1] = (double)h->n_fwd; out3[2] = (double)h->mx_retry_total;
+    h->t_fwd = 0; h->n_fwd = 0; h->mx_retry_total = 0;
     return 0;
 }
 

@@ -72,6 +72,8 @@ struct QpArgs {
     int warm;                 // 1: try an active-set polish from the previous solution of each instance first
     const double *prox;       // per-instance proximal weight added to the diagonal cost (element b * prox_stride), or NULL
     int prox_stride;
+    int n_refine;             // refinement solves per polish (2 in fp64, 3 with fp32 factorisations)
+    double early_ctol;        // tolerance (relative to max(1,|q|inf)) of the look at the un-refined polish solve: its accuracy class
 };
 
 // LDS layout of one QP wave: 5 rotating NX x NX buffers (A_k | Y_k | L_{k,k-1} (also B diag(pi_u)) | Linv_{k-1} | M1 -> Linv_k),
@@ -80,7 +82,7 @@ template <int NX, int NU>
 struct QpLds {
     static constexpr int NZ = NX + NU, MM = NX * NX;
     static constexpr int oA = 0, oY = MM, oL1 = 2 * MM, oP = 3 * MM, oQ = 4 * MM, oB = 5 * MM, oPiS = oB + NX * NU, oVS = oPiS + NZ + NX,
-                         oWp = oVS + NZ + NX, oT1 = oWp + NX, oT2 = oT1 + NX, oT3 = oT2 + NX, oCol = oT3 + NX, TOTAL = oCol + NX + 2;
+                         oWp = oVS + NZ + NX, oT1 = oWp + NX, oT2 = oT1 + NX, oT3 = oT2 + NX, TOTAL = oT3 + NX + 1;
 };
 template <int NX, int NU>
 __host__ __device__ constexpr int qp_lds_doubles(int) { return QpLds<NX, NU>::TOTAL; }
@@ -114,7 +116,7 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
     using Ld = QpLds<NX, NU>;
     constexpr int NZ = NX + NU, SR = NX + 2 * NZ, MM = NX * NX;
     double *sA = sm + Ld::oA, *sY = sm + Ld::oY, *sL1 = sm + Ld::oL1, *sB = sm + Ld::oB, *sPiS = sm + Ld::oPiS, *sVS = sm + Ld::oVS;
-    double *sWp = sm + Ld::oWp, *sT1 = sm + Ld::oT1, *sT2 = sm + Ld::oT2, *sCol = sm + Ld::oCol;
+    double *sWp = sm + Ld::oWp, *sT1 = sm + Ld::oT1, *sT2 = sm + Ld::oT2;
     double *Lprev = sm + Ld::oP, *Lcur = sm + Ld::oQ;
     int fail = 0;
     // software pipeline: stage k+1's blocks are fetched HBM/L2 -> registers while stage k is being processed
@@ -164,7 +166,7 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
             wla::wsync();
             STAMP(3);
-            fail |= wla::spd_inv_gj<NX>(sY, NX, Lcur, NX, sCol, lane);
+            fail |= wla::spd_inv_gj<NX>(sY, NX, Lcur, NX, (double *)nullptr, lane);
             STAMP(4);
             double *Lg = g.Linv + (size_t)k * MM;
 #pragma unroll
@@ -263,6 +265,161 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
 #ifdef NE_STAMP
     if (dbg && lane == 0) for (int i = 0; i < 4; i++) dbg[i] = acc_[i];
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mixed-precision variant of the two sweeps (opts.precision = 1; BASELINE config 3 "fp32 vs fp64"):
+//   fp32: the factorisation (M1, T = M1 Dinv, D_k, Gauss-Jordan inverse), the stored inverses Dinv_k (half the scratch traffic)
+//         and the substitutions with them;
+//   fp64: everything that defines the equations -- the right-hand sides E v - e, the off-diagonal products A (pi .* u), and
+//         G = E' nu -- so the residuals the interior point and the polish see are exact for the iterate they hold.
+// The solves are then fp32-accurate Newton / refinement steps on fp64 residuals: classical mixed-precision iterative refinement.
+// The polish spends one more refinement solve (3 instead of 2) and ends on the same fp64 KKT certificate; what does not certify
+// is solved again by the fp64 kernels (launch_qp).
+// ------------------------------------------------------------------------------------------------
+template <int NX, int NU>
+struct QpLdsMx {   // doubles first (offsets in doubles), then floats (offsets in floats from the float base)
+    static constexpr int NZ = NX + NU, MM = NX * NX;
+    static constexpr int dA = 0, dB = dA + MM, dPiS = dB + NX * NU, dVS = dPiS + NZ + NX, dWp = dVS + NZ + NX, dT1 = dWp + NX, dT2 = dT1 + NX,
+                         dT3 = dT2 + NX, DTOT = dT3 + NX + 1;
+    static constexpr int fA = 0, fM = MM, fP = 2 * MM, fY = 3 * MM, fL1 = 4 * MM, fB = 5 * MM, fPi = fB + NX * NU, fT = fPi + NZ + NX, FTOT = fT + NX + 2;
+    static constexpr size_t BYTES = 8 * (size_t)DTOT + 4 * (size_t)FTOT;
+};
+
+template <int NX, int NU>
+__device__ __forceinline__ int ne_forward_mx(double *smd, const NeG<NX, NU> g, bool factor, double eflag, double delta, int lane, double *bmax_out) {
+    double bmax = 0.0;
+    using Ld = QpLdsMx<NX, NU>;
+    constexpr int NZ = NX + NU, SR = NX + 2 * NZ, MM = NX * NX;
+    double *sA = smd + Ld::dA, *sB = smd + Ld::dB, *sPiS = smd + Ld::dPiS, *sVS = smd + Ld::dVS, *sWp = smd + Ld::dWp, *sT1 = smd + Ld::dT1;
+    float *smf = (float *)(smd + Ld::DTOT);
+    float *fA = smf + Ld::fA, *Lcur = smf + Ld::fM, *Lprev = smf + Ld::fP, *fY = smf + Ld::fY, *fL1 = smf + Ld::fL1, *fB = smf + Ld::fB, *fPi = smf + Ld::fPi,
+          *fT = smf + Ld::fT;
+    float *Linv_g = (float *)g.Linv;
+    int fail = 0;
+    constexpr int RA = (MM + 63) / 64, RB = (NX * NU + 63) / 64;
+    double rA[RA], rB[RB], rPi = 0.0, rV = 0.0, rE = 0.0;
+    float rL[RA];
+    auto prefetch = [&](int k) {
+        const double *Ak = g.A + (size_t)k * MM, *Bk = g.Bm + (size_t)k * NX * NU;
+        const float *Lg = Linv_g + (size_t)k * MM;
+#pragma unroll
+        for (int r = 0; r < RA; r++) rA[r] = Ak[min(r * 64 + lane, MM - 1)];
+#pragma unroll
+        for (int r = 0; r < RB; r++) rB[r] = Bk[min(r * 64 + lane, NX * NU - 1)];
+        if (!factor) {
+#pragma unroll
+            for (int r = 0; r < RA; r++) rL[r] = Lg[min(r * 64 + lane, MM - 1)];
+        }
+        const int ls = min(lane, NZ + NX - 1), lx = min(lane, NX - 1);
+        rPi = g.PI[k * NZ + ls]; rV = g.V[k * NZ + ls];
+        if (eflag != 0.0) rE = 0.5 * (g.ub[k * SR + lx] + g.lb[k * SR + lx]);
+    };
+    prefetch(0);
+    for (int k = 0; k < g.N; k++) {
+#pragma unroll
+        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < MM) { sA[o] = rA[r]; if (factor) fA[o] = (float)rA[r]; else Lcur[o] = rL[r]; } }
+#pragma unroll
+        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) { sB[o] = rB[r]; if (factor) fB[o] = (float)rB[r]; } }
+        if (lane < NZ + NX) { sPiS[lane] = rPi; sVS[lane] = rV; fPi[lane] = (float)rPi; }
+        const double ek = rE;
+        wla::wsync();
+        if (k + 1 < g.N) prefetch(k + 1);
+        if (factor) {
+#pragma unroll
+            for (int o = lane; o < MM; o += 64) Lcur[o] = (k > 0) ? fA[o] * fPi[o % NX] : 0.0f;   // M1 = A diag(pi_x,k)
+            wla::wsync();
+            if (k > 0) {
+                wla::gemm_nt_blk<NX, NX, NX, 3, 2>(Lcur, NX, Lprev, NX, fL1, NX, 1.0f, lane);     // T = M1 Dinv_{k-1}
+                wla::wsync();
+            }
+            wla::build_Y_lower<NX, NU>(Lcur, fA, fB, fPi + NX, fL1, k > 0, fPi + NZ, (float)delta, fY, lane);
+            wla::wsync();
+            fail |= wla::spd_inv_gj<NX>(fY, NX, Lcur, NX, (float *)nullptr, lane);
+            float *Lg = Linv_g + (size_t)k * MM;
+#pragma unroll
+            for (int o = lane; o < MM; o += 64) Lg[o] = Lcur[o];
+        }
+        // right-hand side in fp64: b = A v_x + B v_u - v_x,k+1 - eflag e_k  (+ A (pi_x,k .* u_{k-1}))
+        double b = 0.0;
+        if (lane < NX) {
+            b = -sVS[NZ + lane] - eflag * ek;
+#pragma unroll
+            for (int m = 0; m < NX; m++) b = fma(sA[lane * NX + m], sVS[m], b);
+#pragma unroll
+            for (int m = 0; m < NU; m++) b = fma(sB[lane * NU + m], sVS[NX + m], b);
+        }
+        if (k > 0) {
+            if (lane < NX) sT1[lane] = sWp[lane] * sPiS[lane];
+            wla::wsync();
+            if (lane < NX) {
+#pragma unroll
+                for (int m = 0; m < NX; m++) b = fma(sA[lane * NX + m], sT1[m], b);
+            }
+        }
+        if (lane < NX) fT[lane] = (float)b;
+        bmax = fmax(bmax, fabs(b));
+        wla::wsync();
+        const double w = (double)wla::matvec_row<NX, NX, false>(Lcur, NX, fT, lane);   // u_k = Dinv_k t_k  (fp32)
+        wla::wsync();
+        if (lane < NX) { sWp[lane] = w; g.W[k * NX + lane] = w; }
+        float *t = Lcur; Lcur = Lprev; Lprev = t;
+        wla::wsync();
+    }
+    if (bmax_out) *bmax_out = wla::wave_max(bmax);
+    return fail;
+}
+
+template <int NX, int NU>
+__device__ __forceinline__ void ne_backward_mx(double *smd, const NeG<NX, NU> g, int lane) {
+    using Ld = QpLdsMx<NX, NU>;
+    constexpr int NZ = NX + NU, MM = NX * NX;
+    double *sA = smd + Ld::dA, *sB = smd + Ld::dB, *sPiS = smd + Ld::dPiS, *sWp = smd + Ld::dWp, *sT2 = smd + Ld::dT2, *sT3 = smd + Ld::dT3;
+    float *smf = (float *)(smd + Ld::DTOT);
+    float *sLa = smf + Ld::fM, *fT = smf + Ld::fT;
+    const float *Linv_g = (const float *)g.Linv;
+    if (lane < NX) sT3[lane] = 0.0;
+    wla::wsync();
+    constexpr int RA = (MM + 63) / 64, RB = (NX * NU + 63) / 64;
+    double rA[RA], rB[RB], rPi = 0.0, rW = 0.0;
+    float rL[RA];
+    auto prefetch = [&](int k) {
+        const double *Ak = g.A + (size_t)k * MM, *Bk = g.Bm + (size_t)k * NX * NU;
+        const float *Lg = Linv_g + (size_t)k * MM;
+#pragma unroll
+        for (int r = 0; r < RA; r++) { const int o = min(r * 64 + lane, MM - 1); rA[r] = Ak[o]; rL[r] = Lg[o]; }
+#pragma unroll
+        for (int r = 0; r < RB; r++) rB[r] = Bk[min(r * 64 + lane, NX * NU - 1)];
+        const int lx = min(lane, NX - 1);
+        rPi = g.PI[(k + 1) * NZ + lx]; rW = g.W[k * NX + lx];
+    };
+    prefetch(g.N - 1);
+    for (int k = g.N - 1; k >= 0; k--) {
+#pragma unroll
+        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < MM) { sA[o] = rA[r]; sLa[o] = rL[r]; } }
+#pragma unroll
+        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) sB[o] = rB[r]; }
+        if (lane < NX) { sPiS[lane] = rPi; sWp[lane] = rW; }
+        wla::wsync();
+        if (k > 0) prefetch(k - 1);
+        if (lane < NX) fT[lane] = (float)(sPiS[lane] * sT3[lane]);
+        wla::wsync();
+        const double nu = sWp[lane < NX ? lane : 0] + (double)wla::matvec_row<NX, NX, false>(sLa, NX, fT, lane);
+        wla::wsync();
+        if (lane < NX) {
+            g.W[k * NX + lane] = nu;
+            g.G[(k + 1) * NZ + lane] = sT3[lane] - nu;
+            sT2[lane] = nu;
+        }
+        wla::wsync();
+        const double ga = wla::matvec_row<NX, NX, true>(sA, NX, sT2, lane);     // E' nu in fp64: consistent with the stored nu
+        const double gb = wla::matvec_row<NU, NX, true>(sB, NU, sT2, lane);
+        wla::wsync();
+        if (lane < NX) sT3[lane] = ga;
+        if (lane < NU) g.G[k * NZ + NX + lane] = gb;
+        wla::wsync();
+    }
+    if (lane < NX) g.G[lane] = sT3[lane];
 }
 
 // per-element constants of the stage-ordered primal vector, re-read from L2-resident inputs where needed
@@ -529,7 +686,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         if (phase == P_POL0 && s.pol_fail == 0.0 && s.pol_round < max_rounds) {
             // cheap look at the un-refined solve: if the active set is visibly wrong (coarse tolerance) correct it now and
             // factorise again, without spending the two refinement solves on a set that is about to change
-            const double ctol = 1e-6 * qscale;
+            const double ctol = a.early_ctol * qscale;
             int changed = 0;
     #pragma unroll 4
         for (int e = lane; e < n; e += 64) {
@@ -568,7 +725,9 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 const double r1 = (pi != 0.0) ? el.pd * zn + el.q + CL[e] : 0.0;
                 V[e] = zn - pi * r1;
             }
-            phase = phase + 1;
+            // n_refine refinement solves per polish: P_POL1 repeats until the last one, which runs as P_POL2 (s.pad counts them)
+            if (phase == P_POL0) { s.pad = 0.0; phase = P_POL1; }
+            else { s.pad += 1.0; phase = (s.pad + 1.0 >= (double)a.n_refine) ? P_POL2 : P_POL1; }
         } else {
             double vst = 0.0, vbox = 0.0, vsign = 0.0;
     #pragma unroll 4
@@ -740,6 +899,36 @@ __global__ __launch_bounds__(64) void k_ne_bwd_phase(QpArgs a) {
     wla::wsync_mem();
     phase_update<NX, NU>(a, 0, b, lane);
 #endif
+}
+
+#ifndef QP_MX_WAVES_PER_SIMD
+#define QP_MX_WAVES_PER_SIMD 3
+#endif
+template <int NX, int NU>
+__global__ __launch_bounds__(64, QP_MX_WAVES_PER_SIMD) void k_ne_fwd_mx(QpArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B || (a.run && !a.run[b])) return;
+    QpState *st = (QpState *)a.state + b;
+    const int phase = (int)st->phase;
+    if (phase == P_DONE) return;
+    extern __shared__ double sm[];
+    const bool factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
+    const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
+    double bmax = 0.0;
+    const int f = ne_forward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane, &bmax);
+    if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
+    if (lane == 0) { st->ticks += 1.0; if (factor) { st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
+}
+template <int NX, int NU>
+__global__ __launch_bounds__(64) void k_ne_bwd_phase_mx(QpArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B || (a.run && !a.run[b])) return;
+    const QpState *st = (const QpState *)a.state + b;
+    if ((int)st->phase == P_DONE) return;
+    extern __shared__ double sm[];
+    ne_backward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
+    wla::wsync_mem();
+    phase_update<NX, NU>(a, 0, b, lane);
 }
 
 // ------------------------------------------------------------------------------------------------

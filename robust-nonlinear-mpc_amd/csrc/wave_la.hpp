@@ -10,6 +10,9 @@
 
 namespace wla {
 
+template <typename T> struct ident { using type = T; };
+template <typename T> using ident_t = typename ident<T>::type;
+
 // LDS-only ordering between lanes of the (single) wave of a workgroup.  NOT __syncthreads(): its workgroup fence
 // also waits for every outstanding global load/store (vmcnt(0)), which cost ~86 % of the wave's lifetime in the first
 // profile.  LDS instructions of one wave execute in order, so waiting for lgkmcnt(0) and stopping the compiler from
@@ -67,8 +70,8 @@ __device__ __forceinline__ void gemm(const double *A, int lda, const double *B, 
 
 // C(MxN) = alpha * A(MxK) * B(NxK)' with RBxCB register blocking per lane (one pass, needs ceil(M/RB)*ceil(N/CB) <= 64).
 // Out-of-range rows/cols are clamped on load and masked on store.
-template <int M, int N, int K, int RB, int CB>
-__device__ __forceinline__ void gemm_nt_blk(const double *A, int lda, const double *B, int ldb, double *C, int ldc, double alpha, int lane) {
+template <int M, int N, int K, int RB, int CB, typename T>
+__device__ __forceinline__ void gemm_nt_blk(const T *A, int lda, const T *B, int ldb, T *C, int ldc, ident_t<T> alpha, int lane) {
     constexpr int TR = (M + RB - 1) / RB, TC = (N + CB - 1) / CB;
     static_assert(TR * TC <= 64, "one pass only");
     if (lane < TR * TC) {
@@ -78,14 +81,14 @@ __device__ __forceinline__ void gemm_nt_blk(const double *A, int lda, const doub
         for (int r = 0; r < RB; r++) ri[r] = min(tr * RB + r, M - 1);
 #pragma unroll
         for (int q = 0; q < CB; q++) cj[q] = min(tc * CB + q, N - 1);
-        double acc[RB][CB];
+        T acc[RB][CB];
 #pragma unroll
         for (int r = 0; r < RB; r++)
 #pragma unroll
-            for (int q = 0; q < CB; q++) acc[r][q] = 0.0;
+            for (int q = 0; q < CB; q++) acc[r][q] = T(0);
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            double a[RB], b[CB];
+            T a[RB], b[CB];
 #pragma unroll
             for (int r = 0; r < RB; r++) a[r] = A[ri[r] * lda + k];
 #pragma unroll
@@ -149,9 +152,9 @@ __device__ __forceinline__ void gemm_blk(const double *A, int lda, const double 
 
 // Lower triangle (i >= j) of  Y = M1 A' + B diag(piu) B' - T M1' + diag(d) ,  all NX x NX (B: NX x NU), 2x2 blocks, one pass.
 // useT = false drops the T term.  Only the lower triangle of Y is written (the Cholesky reads nothing else).
-template <int NX, int NU>
-__device__ __forceinline__ void build_Y_lower(const double *M1, const double *A, const double *B, const double *piu, const double *Tm,
-                                              bool useT, const double *d, double delta, double *Y, int lane) {
+template <int NX, int NU, typename R>
+__device__ __forceinline__ void build_Y_lower(const R *M1, const R *A, const R *B, const R *piu, const R *Tm,
+                                              bool useT, const R *d, ident_t<R> delta, R *Y, int lane) {
     constexpr int T = (NX + 1) / 2, NT = T * (T + 1) / 2;
     static_assert(NT <= 64, "one pass only");
     if (lane < NT) {
@@ -160,22 +163,22 @@ __device__ __forceinline__ void build_Y_lower(const double *M1, const double *A,
         while (rem > bi) { rem -= bi + 1; bi++; }
         const int bj = rem;
         const int i0 = bi * 2, i1 = min(i0 + 1, NX - 1), j0 = bj * 2, j1 = min(j0 + 1, NX - 1);
-        double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+        R a00 = 0, a01 = 0, a10 = 0, a11 = 0;
 #pragma unroll
         for (int k = 0; k < NX; k++) {
-            const double x0 = M1[i0 * NX + k], x1 = M1[i1 * NX + k], y0 = A[j0 * NX + k], y1 = A[j1 * NX + k];
+            const R x0 = M1[i0 * NX + k], x1 = M1[i1 * NX + k], y0 = A[j0 * NX + k], y1 = A[j1 * NX + k];
             a00 = fma(x0, y0, a00); a01 = fma(x0, y1, a01); a10 = fma(x1, y0, a10); a11 = fma(x1, y1, a11);
         }
 #pragma unroll
         for (int k = 0; k < NU; k++) {
-            const double pk = piu[k];
-            const double x0 = B[i0 * NU + k] * pk, x1 = B[i1 * NU + k] * pk, y0 = B[j0 * NU + k], y1 = B[j1 * NU + k];
+            const R pk = piu[k];
+            const R x0 = B[i0 * NU + k] * pk, x1 = B[i1 * NU + k] * pk, y0 = B[j0 * NU + k], y1 = B[j1 * NU + k];
             a00 = fma(x0, y0, a00); a01 = fma(x0, y1, a01); a10 = fma(x1, y0, a10); a11 = fma(x1, y1, a11);
         }
         if (useT) {   // - T M1'  (T = M1 Dinv_prev; the product is symmetric)
 #pragma unroll
             for (int k = 0; k < NX; k++) {
-                const double x0 = Tm[i0 * NX + k], x1 = Tm[i1 * NX + k], y0 = M1[j0 * NX + k], y1 = M1[j1 * NX + k];
+                const R x0 = Tm[i0 * NX + k], x1 = Tm[i1 * NX + k], y0 = M1[j0 * NX + k], y1 = M1[j1 * NX + k];
                 a00 = fma(-x0, y0, a00); a01 = fma(-x0, y1, a01); a10 = fma(-x1, y0, a10); a11 = fma(-x1, y1, a11);
             }
         }
@@ -190,9 +193,9 @@ __device__ __forceinline__ void build_Y_lower(const double *M1, const double *A,
 }
 
 // y(M) = op(A)(MxK) x(K)  (lane i < M computes row i).  TA: A stored KxM.
-template <int M, int K, bool TA>
-__device__ __forceinline__ double matvec_row(const double *A, int lda, const double *x, int lane) {
-    double s = 0.0;
+template <int M, int K, bool TA, typename T>
+__device__ __forceinline__ T matvec_row(const T *A, int lda, const T *x, int lane) {
+    T s = T(0);
     if (lane < M) {
 #pragma unroll
         for (int k = 0; k < K; k++) s = fma(TA ? A[k * lda + lane] : A[lane * lda + k], x[k], s);
@@ -215,6 +218,15 @@ __device__ __forceinline__ double fast_rsq(double x) {
     r = r * fma(-h * r, r, 1.5);
     return r;
 }
+__device__ __forceinline__ float fast_rcp(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float readlane_d(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float bperm_d(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
+template <typename T> __device__ __forceinline__ T tiny_pivot();
+template <> __device__ __forceinline__ double tiny_pivot<double>() { return 1e-300; }
+template <> __device__ __forceinline__ float tiny_pivot<float>() { return 1e-30f; }
 // broadcast lane `l` (compile-time / wave-uniform) of a double through SGPRs: no LDS, no waitcnt
 __device__ __forceinline__ double readlane_d(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -234,8 +246,8 @@ __device__ __forceinline__ double bperm_d(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
-template <int M>
-__device__ __forceinline__ int spd_inv_gj(const double *Y, int ld, double *Dinv, int ldi, double * /*col*/, int lane) {
+template <int M, typename R>
+__device__ __forceinline__ int spd_inv_gj(const R *Y, int ld, R *Dinv, int ldi, R * /*col*/, int lane) {
     // Block (2x2 pivots) symmetric Gauss-Jordan sweep: T = ceil(M/2) rounds instead of M; branch-free.
     //   P = A_JJ ;  A_IL -= A_IJ P^-1 A_JL (I,L not J) ;  A_IJ <- A_IJ P^-1 ;  A_JL <- P^-1 A_JL ;  A_JJ <- -P^-1 ;  result = -A^-1
     constexpr int T = (M + 1) / 2, NT = T * (T + 1) / 2;
@@ -246,13 +258,13 @@ __device__ __forceinline__ int spd_inv_gj(const double *Y, int ld, double *Dinv,
     const bool act = lane < NT;
     const int i0 = 2 * bi, i1 = i0 + 1, l0 = 2 * bj, l1 = l0 + 1;
     // padded (2T x 2T) matrix: identity in the padding row/col when M is odd
-    auto ld_el = [&](int i, int l) -> double {
+    auto ld_el = [&](int i, int l) -> R {
         const bool pad = (i >= M) | (l >= M);
         const int ii = min(i, M - 1), ll = min(l, M - 1);
-        const double v = (ii >= ll) ? Y[ii * ld + ll] : Y[ll * ld + ii];
-        return pad ? ((i == l) ? 1.0 : 0.0) : v;
+        const R v = (ii >= ll) ? Y[ii * ld + ll] : Y[ll * ld + ii];
+        return pad ? ((i == l) ? R(1) : R(0)) : v;
     };
-    double a00 = ld_el(i0, l0), a01 = ld_el(i0, l1), a10 = ld_el(i1, l0), a11 = ld_el(i1, l1);
+    R a00 = ld_el(i0, l0), a01 = ld_el(i0, l1), a10 = ld_el(i1, l0), a11 = ld_el(i1, l1);
     const int tri_bi = bi * (bi + 1) / 2, tri_bj = bj * (bj + 1) / 2;
     int fail = 0;
 #pragma unroll
@@ -261,29 +273,29 @@ __device__ __forceinline__ int spd_inv_gj(const double *Y, int ld, double *Dinv,
         // C_I = A_{I,J} (2x2): lane (bi, jb) if bi > jb, else lane (jb, bi) transposed;  C_L = A_{L,J} likewise.  Issued first so the
         // crossbar round trip overlaps the dependent reciprocal chain of the pivot block below.
         const int srcI = (bi >= jb) ? tri_bi + jb : tri_jb + bi, srcL = (bj >= jb) ? tri_bj + jb : tri_jb + bj;
-        const double f00 = bperm_d(a00, srcI), f01 = bperm_d(a01, srcI), f10 = bperm_d(a10, srcI), f11 = bperm_d(a11, srcI);
-        const double g00 = bperm_d(a00, srcL), g01 = bperm_d(a01, srcL), g10 = bperm_d(a10, srcL), g11 = bperm_d(a11, srcL);
+        const R f00 = bperm_d(a00, srcI), f01 = bperm_d(a01, srcI), f10 = bperm_d(a10, srcI), f11 = bperm_d(a11, srcI);
+        const R g00 = bperm_d(a00, srcL), g01 = bperm_d(a01, srcL), g10 = bperm_d(a10, srcL), g11 = bperm_d(a11, srcL);
         __builtin_amdgcn_sched_barrier(0);
         // pivot block (uniform): P = [[pa, pb],[pb, pc]] from the diagonal lane; P^-1 by two scalar eliminations (as stable as 1x1 pivots)
-        const double pa = readlane_d(a00, dl), pb = readlane_d(a10, dl), pc = readlane_d(a11, dl);
-        double d1 = pa;
-        if (!(d1 > 1e-300)) { fail = 1; d1 = 1e-300; }
-        const double r1 = fast_rcp(d1), bp = pb * r1;
-        double d2 = fma(-pb, bp, pc);
-        if (!(d2 > 1e-300)) { fail = 1; d2 = 1e-300; }
-        const double r2 = fast_rcp(d2);
-        const double q11 = r2, q01 = -bp * r2, q00 = fma(bp * bp, r2, r1);      // P^-1 = [[q00, q01],[q01, q11]]
+        const R pa = readlane_d(a00, dl), pb = readlane_d(a10, dl), pc = readlane_d(a11, dl);
+        R d1 = pa;
+        if (!(d1 > tiny_pivot<R>())) { fail = 1; d1 = tiny_pivot<R>(); }
+        const R r1 = fast_rcp(d1), bp = pb * r1;
+        R d2 = fma(-pb, bp, pc);
+        if (!(d2 > tiny_pivot<R>())) { fail = 1; d2 = tiny_pivot<R>(); }
+        const R r2 = fast_rcp(d2);
+        const R q11 = r2, q01 = -bp * r2, q00 = fma(bp * bp, r2, r1);      // P^-1 = [[q00, q01],[q01, q11]]
         const bool tI = bi < jb, tL = bj < jb;
-        const double ci00 = f00, ci01 = tI ? f10 : f01, ci10 = tI ? f01 : f10, ci11 = f11;
-        const double cl00 = g00, cl01 = tL ? g10 : g01, cl10 = tL ? g01 : g10, cl11 = g11;
+        const R ci00 = f00, ci01 = tI ? f10 : f01, ci10 = tI ? f01 : f10, ci11 = f11;
+        const R cl00 = g00, cl01 = tL ? g10 : g01, cl10 = tL ? g01 : g10, cl11 = g11;
         // general update: B -= (C_I P^-1) C_L'
-        const double t00 = fma(ci00, q00, ci01 * q01), t01 = fma(ci00, q01, ci01 * q11);
-        const double t10 = fma(ci10, q00, ci11 * q01), t11 = fma(ci10, q01, ci11 * q11);
-        const double n00 = fma(-t00, cl00, fma(-t01, cl01, a00)), n01 = fma(-t00, cl10, fma(-t01, cl11, a01));
-        const double n10 = fma(-t10, cl00, fma(-t11, cl01, a10)), n11 = fma(-t10, cl10, fma(-t11, cl11, a11));
+        const R t00 = fma(ci00, q00, ci01 * q01), t01 = fma(ci00, q01, ci01 * q11);
+        const R t10 = fma(ci10, q00, ci11 * q01), t11 = fma(ci10, q01, ci11 * q11);
+        const R n00 = fma(-t00, cl00, fma(-t01, cl01, a00)), n01 = fma(-t00, cl10, fma(-t01, cl11, a01));
+        const R n10 = fma(-t10, cl00, fma(-t11, cl01, a10)), n11 = fma(-t10, cl10, fma(-t11, cl11, a11));
         // block column jb (rows below the pivot): B <- B P^-1 ; block row jb (cols left of the pivot): B <- P^-1 B
-        const double c00 = fma(a00, q00, a01 * q01), c01 = fma(a00, q01, a01 * q11), c10 = fma(a10, q00, a11 * q01), c11 = fma(a10, q01, a11 * q11);
-        const double w00 = fma(q00, a00, q01 * a10), w01 = fma(q00, a01, q01 * a11), w10 = fma(q01, a00, q11 * a10), w11 = fma(q01, a01, q11 * a11);
+        const R c00 = fma(a00, q00, a01 * q01), c01 = fma(a00, q01, a01 * q11), c10 = fma(a10, q00, a11 * q01), c11 = fma(a10, q01, a11 * q11);
+        const R w00 = fma(q00, a00, q01 * a10), w01 = fma(q00, a01, q01 * a11), w10 = fma(q01, a00, q11 * a10), w11 = fma(q01, a01, q11 * a11);
         const bool isD = (bi == jb) & (bj == jb), inC = (bj == jb) & !isD, inR = (bi == jb) & !isD;
         a00 = isD ? -q00 : (inC ? c00 : (inR ? w00 : n00));
         a01 = isD ? -q01 : (inC ? c01 : (inR ? w01 : n01));

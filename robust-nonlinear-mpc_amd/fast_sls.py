@@ -50,6 +50,8 @@ class BatchedFastSLS:
         self.opts = L.Opts()
         self.lib.slsqp_default_opts(C.byref(self.opts))
         self.opts.rti_steps = 0       # fast_SLS default: iterate to convergence (fast_SLS_jit.py:214)
+        import os
+        self.opts.precision = int(os.environ.get("SLSQP_PRECISION", "0"))   # 0 fp64, 1 mixed fp32/fp64 (see include/slsqp.h)
         self.verbose = False
         self.save_it_data = False
         self.CONV_EPS = 1e-6
@@ -124,6 +126,7 @@ class BatchedFastSLS:
         """(total ms, launches) of the dominant kernel k_ne_fwd since the last call (HIP events on the handle's stream)."""
         t = np.zeros(3)
         self.lib.slsqp_kernel_timing(self.h, _ptr(t))
+        self.mx_retries = int(t[2])      # instances re-solved in fp64 after a mixed-precision attempt (opts.precision = 1)
         return t[0], int(t[1])
 
     def solve(self, x0, fetch=True):

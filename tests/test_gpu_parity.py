@@ -239,6 +239,50 @@ def test_closed_loop_scp_converge_mode_vs_oracle(model, N, steps, sls_steps):
     assert len({tuple(r) for r in out["scp_iterations"]}) >= 1
 
 
+@pytest.mark.parametrize("model,B", [("quadrotor", 64), ("rocket", 32)])
+def test_mixed_precision_matches_fp64_and_oracle(model, B):
+    """BASELINE config 3 ("fp32 vs fp64"): opts.precision = 1 runs the block factorisations, the stored inverses and the substitutions
+    in fp32 and keeps right-hand sides, residuals and the KKT certificate in fp64 (mixed-precision iterative refinement).  Because the
+    certificate is fp64, a certified result must agree with the fp64 solver to the same 1e-6 the fp64 path is held to -- for every
+    interior-point tolerance of the sweep -- and with the CPU oracle."""
+    from robust_nonlinear_mpc_amd import make_batch
+    batch = make_batch(model, os.path.join(GOLDEN, {"quadrotor": "sweep_quadrotor_N20_s0.npz", "rocket": "sweep_rocket_N20_s0.npz"}[model]), B, seed=7)
+    m, N = batch["model"], batch["N"]
+    from robust_nonlinear_mpc_amd import BatchedFastSLS
+    f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=B)
+    f.update_dynamics_list(batch["A"], batch["B"], batch["E"], batch["g"], batch["gN"], batch["c"])
+    f.update_linear_cost(batch["q"])
+    x0 = batch["x0_arg"]
+    ub, lb = f.get("ubg", (f.mb,)), f.get("lbg", (f.mb,))
+    l = np.concatenate([lb, -x0 - 1e-10], axis=1)
+    u = np.concatenate([ub, -x0 + 1e-10], axis=1)
+    f.qp_update_data_vec(batch["q"], l, u)
+    f.opts.warm_start = 0
+    f.opts.precision, f.opts.qp_eps = 0, 1e-9
+    xr, yr, st, it, _ = f.qp_solve()
+    assert (st == 0).all()
+    for eps in (1e-3, 1e-5, 1e-6, 1e-9):
+        f.opts.precision, f.opts.qp_eps = 1, eps
+        f.kernel_timing()
+        x, y, st, it, _ = f.qp_solve()
+        f.kernel_timing()
+        kk = f.get("kkt", (8,))
+        assert (st == 0).all(), (eps, np.bincount(st))
+        assert kk[:, :3].max() < 1e-8 * max(1.0, np.abs(batch["q"]).max())
+        for b in range(B):
+            assert relerr(x[b], xr[b]) < 1e-6, (eps, b, relerr(x[b], xr[b]))
+            assert relerr(y[b], yr[b]) < 1e-5 * max(1.0, np.abs(yr[b]).max()), (eps, b)
+    # two instances against the independent CPU solver (OSQP-class restatement driven to 1e-9)
+    from oracle import oracle as O
+    d = O.dims_of(m.nx, m.nu, m.nw, N, m.ni, m.ni_f)
+    for b in range(2):
+        xo, yo, info = O.qp_solve(d, batch["A"][b], batch["B"][b], m.G, m.Gf, m.Q, m.R, m.Qf, batch["q"][b], np.maximum(l[b], -1e20), np.minimum(u[b], 1e20),
+                                  O.tight_settings())
+        assert info.status in (1, 2)
+        assert relerr(x[b], xo) < 1e-6
+    f.close()
+
+
 def _nlp_kkt_residual(m, N, X, U, x_meas):
     """Independent certificate for the nominal NLP (solver/nlp.py:158-217): dynamics defect, box violation, and the stationarity
     residual min over multipliers (nu free, lambda >= 0 on active bounds only) of |2 H y + J' nu + sum_active +-lambda|."""

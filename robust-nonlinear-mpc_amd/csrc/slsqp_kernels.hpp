@@ -1006,12 +1006,15 @@ struct SweepArgs {
 
 template <int NX, int NU>
 __host__ __device__ constexpr int sweep_lds_doubles() {
-    // sA sS sYm sAcl sSn sPhi sPhi2 (7 NX^2, NW == NX) + sB sX sF sK sPu (5 NX NU) + sH (NU^2) + sC (NX+NU)
-    return 7 * NX * NX + 5 * NX * NU + NU * NU + (NX + NU) + 8;
+    // sA sS sYm sAcl (4 NX^2; the propagate phase reuses sS / sYm for Phi, NW == NX) + sB sX sF sK sPu (5 NX NU) + sH (NU^2) + sC (NX+NU)
+    return 4 * NX * NX + 5 * NX * NU + NU * NU + (NX + NU) + 8;
 }
 
+#ifndef SWEEP_WAVES_PER_SIMD
+#define SWEEP_WAVES_PER_SIMD 3
+#endif
 template <int NX, int NU>
-__global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
+__global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a) {
     using L = Lay<NX, NU>;
     constexpr int NZ = L::NZ, NI = L::NI, NIF = L::NIF, NW = NX;
     const int N = a.N, lane = threadIdx.x;
@@ -1035,7 +1038,8 @@ __global__ __launch_bounds__(64) void k_sweep(SweepArgs a) {
     extern __shared__ double sm[];
     double *p = sm;
     double *sA = p; p += NX * NX; double *sS = p; p += NX * NX; double *sYm = p; p += NX * NX; double *sAcl = p; p += NX * NX;
-    double *sSn = p; p += NX * NX; double *sPhi = p; p += NX * NW; double *sPhi2 = p; p += NX * NW;
+    double *sSn = sA;                      // y (A + B K) lands where A_k was: A_k is dead once Acl is formed
+    double *sPhi = sS, *sPhi2 = sYm;       // the Riccati buffers are dead in the propagate phase
     double *sB = p; p += NX * NU; double *sX = p; p += NX * NU; double *sF = p; p += NX * NU; double *sK = p; p += NX * NU;
     double *sPu = p; p += NU * NW; double *sH = p; p += NU * NU; double *sC = p; p += NZ;
     const double *gA = a.A + (size_t)b * N * NX * NX, *gB = a.Bm + (size_t)b * N * NX * NU;

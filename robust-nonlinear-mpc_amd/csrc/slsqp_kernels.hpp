@@ -76,12 +76,12 @@ struct QpArgs {
     double early_ctol;        // tolerance (relative to max(1,|q|inf)) of the look at the un-refined polish solve: its accuracy class
 };
 
-// LDS layout of one QP wave: 5 rotating NX x NX buffers (A_k | Y_k | L_{k,k-1} (also B diag(pi_u)) | Linv_{k-1} | M1 -> Linv_k),
+// LDS layout of one QP wave: 4 NX x NX buffers (A_k | T = M1 Dinv_{k-1} | Dinv_{k-1}, then D_k | M1 -> Dinv_k; the last two rotate),
 // B_k, and a handful of stage vectors.  Everything of size n (IPM vectors) lives in an HBM/L2 workspace.
 template <int NX, int NU>
 struct QpLds {
     static constexpr int NZ = NX + NU, MM = NX * NX;
-    static constexpr int oA = 0, oY = MM, oL1 = 2 * MM, oP = 3 * MM, oQ = 4 * MM, oB = 5 * MM, oPiS = oB + NX * NU, oVS = oPiS + NZ + NX,
+    static constexpr int oA = 0, oL1 = MM, oP = 2 * MM, oQ = 3 * MM, oB = 4 * MM, oPiS = oB + NX * NU, oVS = oPiS + NZ + NX,
                          oWp = oVS + NZ + NX, oT1 = oWp + NX, oT2 = oT1 + NX, oT3 = oT2 + NX, TOTAL = oT3 + NX + 1;
 };
 template <int NX, int NU>
@@ -115,7 +115,7 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
 #endif
     using Ld = QpLds<NX, NU>;
     constexpr int NZ = NX + NU, SR = NX + 2 * NZ, MM = NX * NX;
-    double *sA = sm + Ld::oA, *sY = sm + Ld::oY, *sL1 = sm + Ld::oL1, *sB = sm + Ld::oB, *sPiS = sm + Ld::oPiS, *sVS = sm + Ld::oVS;
+    double *sA = sm + Ld::oA, *sL1 = sm + Ld::oL1, *sB = sm + Ld::oB, *sPiS = sm + Ld::oPiS, *sVS = sm + Ld::oVS;
     double *sWp = sm + Ld::oWp, *sT1 = sm + Ld::oT1, *sT2 = sm + Ld::oT2;
     double *Lprev = sm + Ld::oP, *Lcur = sm + Ld::oQ;
     int fail = 0;
@@ -163,6 +163,8 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             }
             STAMP(2);
             // lower(D_k) = M1 A' + B diag(pi_u) B' + diag(pi_x,k+1) + delta - T M1'      (block LDL': D_k = Y_kk - O D_{k-1}^-1 O')
+            // D_k is built where Dinv_{k-1} was (dead once T is formed: u_{k-1} is kept in sWp), inverted from there into M1's buffer
+            double *sY = Lprev;
             wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
             wla::wsync();
             STAMP(3);

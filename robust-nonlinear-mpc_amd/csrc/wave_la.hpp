@@ -10,6 +10,9 @@
 
 namespace wla {
 
+#ifndef NE_KUNROLL
+#define NE_KUNROLL 32
+#endif
 template <typename T> struct ident { using type = T; };
 template <typename T> using ident_t = typename ident<T>::type;
 
@@ -86,7 +89,7 @@ __device__ __forceinline__ void gemm_nt_blk(const T *A, int lda, const T *B, int
         for (int r = 0; r < RB; r++)
 #pragma unroll
             for (int q = 0; q < CB; q++) acc[r][q] = T(0);
-#pragma unroll
+#pragma unroll NE_KUNROLL
         for (int k = 0; k < K; k++) {
             T a[RB], b[CB];
 #pragma unroll
@@ -169,7 +172,7 @@ __device__ __forceinline__ void build_Y_lower(const R *M1, const R *A, const R *
         const int bj = rem;
         const int i0 = bi * 2, i1 = min(i0 + 1, NX - 1), j0 = bj * 2, j1 = min(j0 + 1, NX - 1);
         R a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-#pragma unroll
+#pragma unroll NE_KUNROLL
         for (int k = 0; k < NX; k++) {
             const R x0 = M1[i0 * NX + k], x1 = M1[i1 * NX + k], y0 = A[j0 * NX + k], y1 = A[j1 * NX + k];
             a00 = fma(x0, y0, a00); a01 = fma(x0, y1, a01); a10 = fma(x1, y0, a10); a11 = fma(x1, y1, a11);
@@ -181,7 +184,7 @@ __device__ __forceinline__ void build_Y_lower(const R *M1, const R *A, const R *
             a00 = fma(x0, y0, a00); a01 = fma(x0, y1, a01); a10 = fma(x1, y0, a10); a11 = fma(x1, y1, a11);
         }
         if (useT) {   // - T M1'  (T = M1 Dinv_prev; the product is symmetric)
-#pragma unroll
+#pragma unroll NE_KUNROLL
             for (int k = 0; k < NX; k++) {
                 const R x0 = Tm[i0 * NX + k], x1 = Tm[i1 * NX + k], y0 = M1[j0 * NX + k], y1 = M1[j1 * NX + k];
                 a00 = fma(-x0, y0, a00); a01 = fma(-x0, y1, a01); a10 = fma(-x1, y0, a10); a11 = fma(-x1, y1, a11);

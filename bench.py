@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--model", default="rocket")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--slices", type=int, default=3, help="independent slices of the rank's batch, each with its own handle / HIP stream / host thread")
     ap.add_argument("--precision", type=int, default=0, help="0: fp64 (headline); 1: mixed fp32 factorisation / fp64 residuals (secondary figure)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
@@ -94,17 +95,25 @@ def main():
             dist.init_process_group(args.backend)
 
     from robust_nonlinear_mpc_amd import BatchedFastSLS, make_batch
-    from robust_nonlinear_mpc_amd.fast_sls import DeviceBatch
+    from robust_nonlinear_mpc_amd.fast_sls import SlicedDeviceBatch
     fixture = os.path.join(ROOT, "tests", "golden", FIXTURE[args.model])
     B = args.batch
     batch = make_batch(args.model, fixture, B, seed=1234 + rank)
     m, N = batch["model"], batch["N"]
-    f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=B, device=local_rank)
-    f.set_rti_steps(m.fast_sls_rti_steps if args.model == "rocket" else 1)
-    f.opts.warm_rounds = int(os.environ.get('QP_WARM_ROUNDS', '4'))
-    f.opts.precision = args.precision
-    f.opts.warm_start = 0   # QP#1 of every step is solved cold (fresh Monte-Carlo instances); QP#2 warm-starts from QP#1
-    dev = DeviceBatch(f, batch)
+
+    def make_solver(nb):
+        f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=nb, device=local_rank)
+        f.set_rti_steps(m.fast_sls_rti_steps if args.model == "rocket" else 1)
+        f.opts.warm_rounds = int(os.environ.get('QP_WARM_ROUNDS', '4'))
+        f.opts.precision = args.precision
+        f.opts.warm_start = 0   # QP#1 of every step is solved cold (fresh Monte-Carlo instances); QP#2 warm-starts from QP#1
+        return f
+
+    # the rank's 4096 instances as `--slices` independent slices (own handle / HIP stream / host thread each): instances are
+    # independent, so one slice's few-instance solver tails overlap the other slices' bulk launches (fast_sls.SlicedDeviceBatch)
+    dev = SlicedDeviceBatch(make_solver, batch, args.slices)
+    f0 = dev.solvers[0]
+    n_var, n_con = f0.n, f0.mb + m.nx
 
     def barrier():
         if world > 1:
@@ -112,7 +121,7 @@ def main():
         torch.cuda.synchronize()
 
     def collect():
-        u0 = dev.fetch_device("primal_vec", (f.n,))[:, m.nx:m.nx + m.nu].contiguous()
+        u0 = dev.fetch_device("primal_vec", (n_var,))[:, m.nx:m.nx + m.nu].contiguous()
         if world > 1:
             src = u0 if args.backend == "nccl" else u0.cpu()
             gathered = [torch.empty_like(src) for _ in range(world)]
@@ -120,76 +129,79 @@ def main():
             return gathered
         return u0
 
-    for _ in range(args.warmup):
-        dev.step()
+    dev.run(args.warmup)
     collect()   # warm the gather path too (first-use kernel loads are not part of the step)
     barrier()
-    t_qp = t_sw = t_tot = 0.0
-    f.kernel_timing()   # reset the per-kernel accumulators
-    host_ms = []
+    dev.kernel_timing()   # reset the per-kernel accumulators
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        dev.step()
-        host_ms.append(1e3 * (time.perf_counter() - ts))
-        tm = f.timing_ms()
-        t_qp += tm["qp"]
-        t_sw += tm["sweep"]
-        t_tot += tm["total"]
+    acc = dev.run(args.steps)
     collect()
     barrier()
     dt = time.perf_counter() - t0
-    fwd_total_ms, fwd_launches = f.kernel_timing()
+    fwd_total_ms, fwd_launches, inst_sweeps, mx_retries = dev.kernel_timing()
     if world > 1:
         tmax = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    st = f.get("status", (), np.int32)
-    its = f.get("qp_iters", (), np.int32)
+    st = dev.get("status", (), np.int32)
+    its = dev.get("qp_iters", (), np.int32)
     qps_per_step = 2 * B            # RTI: QP#1 + QP#2 per instance
-    launches = 2 * args.steps
+    n_sl = len(dev.slices)
     value = qps_per_step * world * args.steps / dt
     out = {
         "metric": "QP solves/sec (whole node), rockETH N=20 batch=4096 RTI MPC step", "value": value, "unit": "QP solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 0 else "f32 factorisation + f64 residuals (mixed)", "data": "synthetic",
         "config": {"workload": f"{args.model} N={N} batch={B}/GPU, fast-SLS RTI step (rti_steps=1: 2 QP solves + 1 SLS sweep per instance)",
-                   "qp_n": f.n, "qp_m": f.mb + m.nx, "solved_frac": float(np.mean((st == 0) | (st == 4))),
+                   "qp_n": n_var, "qp_m": n_con, "slices_per_gpu": n_sl, "solved_frac": float(np.mean((st == 0) | (st == 4))),
                    "polished_frac": float(np.mean(st == 0)), "ipm_iters_mean_last_qp": float(its.mean()), "ipm_iters_max_last_qp": int(its.max()),
-                   "qp2_cold_fallback_frac": float(np.mean(its > 0)), "tightened_frac": float(np.mean(f.get("backoff_x", (N + 1, m.nx)).max(axis=(1, 2)) > 0))},
+                   "qp2_cold_fallback_frac": float(np.mean(its > 0)), "tightened_frac": float(np.mean(dev.get("backoff_x", (N + 1, m.nx)).max(axis=(1, 2)) > 0))},
     }
     if rank == 0:
-        kk = f.get("kkt", (8,))
-        # dominant kernel: k_ne_fwd (block-tridiagonal forward sweep; re-factorises in half of its launches).  Algorithmic bytes
-        # of one launch = for every instance that does work: A_k,B_k of all stages in, rhs slices (Pi, v) in, u out.
+        kk = dev.get("kkt", (8,))
+        # dominant kernel: k_ne_fwd (block-tridiagonal forward sweep; re-factorises in half of its launches).  Algorithmic bytes of one
+        # instance sweep: A_k,B_k of all stages in, rhs slices (Pi, v) in, u out; a launch moves that for every instance it works on
+        # (device counter of instance sweeps / launches); time = HIP events around every launch on the launching stream.
         nz = m.nx + m.nu
-        per_inst = 8 * (N * m.nx * nz + 2 * f.n + N * m.nx)
+        per_inst = 8 * (N * m.nx * nz + 2 * n_var + N * m.nx)
         fwd_ms = fwd_total_ms / max(1, fwd_launches)
-        inst_launches_last_qp = float(kk[:, 7].sum())           # instance-launches of the last QP solve (device counters)
-        # all QP solves of the timed region: scale the last solve's instance-launch count by the measured launch counts
-        alg_bytes_launch = per_inst * inst_launches_last_qp / max(1.0, kk[:, 7].max())
+        alg_bytes_launch = per_inst * float(inst_sweeps) / max(1, fwd_launches)
         achieved = alg_bytes_launch / (fwd_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("k_ne_fwd_bytes_per_launch")
-        qp_ms = t_qp / launches
-        # fp64 work of one QP solve: 28.6 kflop per factorised stage, 2 kflop per solve-only stage sweep
-        flop_last = float((kk[:, 6] * N * 28.6e3 + (kk[:, 7] - kk[:, 6]) * N * 2.0e3 + kk[:, 7] * N * 2.0e3).sum())
+        solves = 2 * args.steps * n_sl                          # QP solve calls in the timed region (each over one slice)
+        qp_ms = sum(a["qp"] for a in acc) / solves
+        sw_ms = sum(a["sweep"] for a in acc) / (args.steps * n_sl)
         out["roofline"] = {"bound": "hbm", "kernel": "k_ne_fwd", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                            "traffic": traffic, "avg_launch_ms": fwd_ms, "launches": fwd_launches, "algorithmic_bytes_per_launch": alg_bytes_launch,
-                           "qp_solve": {"avg_ms": qp_ms, "algorithmic_bytes": QP_BYTES[args.model] * B,
-                                        "achieved_GBps": QP_BYTES[args.model] * B / (qp_ms * 1e-3) / 1e9},
-                           "fp64": {"achieved_TFLOPs_last_qp": flop_last / (qp_ms * 1e-3) / 1e12 if qp_ms > 0 else None, "peak_TFLOPs": 78.6,
-                                    "note": "vector fp64 peak from BASELINE.md (AMD public figure); the guide lists no fp64 peak"},
-                           "sweep_avg_launch_ms": t_sw / args.steps, "solve_call_gpu_ms": t_tot / args.steps,
-                           "host_ms_per_step": [round(x, 2) for x in host_ms]}
+                           "qp_solve": {"avg_ms": qp_ms, "instances": B / n_sl, "algorithmic_bytes": QP_BYTES[args.model] * B / n_sl,
+                                        "achieved_GBps": QP_BYTES[args.model] * B / n_sl / (qp_ms * 1e-3) / 1e9,
+                                        "note": "one solve call = one slice; slices run concurrently, so these times overlap"},
+                           "last_qp_block_solves_per_instance": {"factorising": float(kk[:, 6].mean()), "all": float(kk[:, 7].mean())},
+                           "sweep_avg_launch_ms": sw_ms, "slice_gpu_ms_per_step": [round(a["total"] / args.steps, 2) for a in acc]}
+        if n_sl > 1:
+            # the same kernel with the whole batch in ONE slice (no concurrent launches), two extra steps outside the timed region: with
+            # several slices the HIP-event duration of a launch includes the time it shares the GPU with the other slices' launches
+            pmc1 = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_single_slice.json")
+            one = SlicedDeviceBatch(make_solver, batch, 1)
+            one.run(1)
+            one.kernel_timing()
+            one.run(2)
+            ms1, n1, sw1, _ = one.kernel_timing()
+            one.close()
+            a1 = per_inst * float(sw1) / max(1, n1) / (ms1 / max(1, n1) * 1e-3) / 1e9
+            out["roofline"]["single_slice"] = {"achieved": a1, "frac": a1 / 8000.0, "avg_launch_ms": ms1 / max(1, n1), "launches": n1,
+                                               "algorithmic_bytes_per_launch": per_inst * float(sw1) / max(1, n1),
+                                               "traffic": json.load(open(pmc1)).get("k_ne_fwd_bytes_per_launch") if os.path.exists(pmc1) else None,
+                                               "note": "whole batch as one slice, 2 steps after the timed region (profiles/r01: v4_kernel_stats.csv, pmc_traffic_single_slice.json)"}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(batch, min(B, 4096), budget_s=12.0)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    f.close()
+    dev.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -60,6 +60,7 @@ struct slsqp_handle {
     int n_kev;
     double t_total, t_qp, t_sweep, t_fwd; int n_fwd; double fwd_inst;   // fwd_inst: sum over launches of instances that did work
     std::map<std::string, std::pair<void *, size_t>> named;  // name -> (device ptr, bytes per instance)
+    unsigned long long *inst_launches;                       // device counter: instance-sweeps done by k_ne_fwd (roofline accounting)
 };
 
 static Costs costs_of(slsqp_handle *h) {
@@ -119,6 +120,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->retry, B); h->mx_retry = 0; h->mx_retry_total = 0;
     rc |= dalloc(&h->nom_st, B * 12); rc |= dalloc(&h->nom_need_lin, B); rc |= dalloc(&h->nom_status, B); rc |= dalloc(&h->nom_iters, B);
     rc |= dalloc(&h->mapA, (size_t)N * nx * nx); rc |= dalloc(&h->mapB, (size_t)N * nx * nu);
+    rc |= dalloc(&h->inst_launches, (size_t)1);
     if (rc) { delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
     h->kev.resize(2 * 256); for (auto &e : h->kev) hipEventCreate(&e);
@@ -168,6 +170,7 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     if (!h) return;
     hipSetDevice(h->dev);
     hipStreamSynchronize(h->st);
+    hipFree(h->inst_launches);
     void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->g_raw, h->Xn, h->Un, h->xmeas, h->x0arg, h->u0, h->wbuf, h->u_init, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
                     h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->ws, h->qpstate, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
                     h->backoff_u, h->K, h->status, h->iters, h->itnum, h->has_prev, h->conv, h->alive, h->mask, h->success, h->infeas,
@@ -353,7 +356,7 @@ __global__ void k_mark_retry(int B, const int *run, const int *status, int *retr
 
 static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr) {
     QpArgs a;
-    a.prox = prox; a.prox_stride = 12;
+    a.prox = prox; a.prox_stride = 12; a.inst_launches = h->inst_launches;
     a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;
     a.cst = costs_of(h); a.Linv = h->Linv; a.ws = h->ws; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
     a.status = h->status; a.iters = h->iters; a.max_iter = o->qp_max_iter; a.eps = o->qp_eps;
@@ -475,7 +478,11 @@ extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms4) {
     return 0;
 }
 extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out3) {
-    out3[0] = h->t_fwd; out3[1] = (double)h->n_fwd; out3[2] = (double)h->mx_retry_total;
+    unsigned long long il = 0;
+    hipSetDevice(h->dev);
+    hipMemcpy(&il, h->inst_launches, sizeof(il), hipMemcpyDeviceToHost);
+    hipMemset(h->inst_launches, 0, sizeof(il));
+    out3[0] = h->t_fwd; out3[1] = (double)h->n_fwd; out3[2] = (double)h->mx_retry_total; out3[3] = (double)il;
     h->t_fwd = 0; h->n_fwd = 0; h->mx_retry_total = 0;
     return 0;
 }

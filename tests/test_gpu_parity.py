@@ -283,6 +283,36 @@ def test_mixed_precision_matches_fp64_and_oracle(model, B):
     f.close()
 
 
+def test_sliced_batch_is_bitwise_the_single_slice_result():
+    """bench.py / Monte-Carlo runs cut a rank's batch into independent slices (own handle, stream and host thread each) that advance
+    without lockstep.  An instance is always computed by one wavefront from its own data, so slicing must not change a single bit."""
+    from robust_nonlinear_mpc_amd import BatchedFastSLS, make_batch
+    from robust_nonlinear_mpc_amd.fast_sls import SlicedDeviceBatch
+    B = 96
+    batch = make_batch("quadrotor", os.path.join(GOLDEN, "sweep_quadrotor_N20_s0.npz"), B, seed=3)
+    m, N = batch["model"], batch["N"]
+
+    def make_solver(nb):
+        f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=nb)
+        f.set_rti_steps(1)
+        f.opts.warm_start = 0
+        return f
+
+    res = {}
+    for K in (1, 3):
+        dev = SlicedDeviceBatch(make_solver, batch, K)
+        acc = dev.run(2)
+        assert len(acc) == K and all(a["qp"] > 0 for a in acc)
+        res[K] = {k: dev.get(k, shp) for k, shp in (("primal_vec", (dev.solvers[0].n,)), ("dual_vec", (dev.solvers[0].mb,)), ("backoff", (N, m.ni)))}
+        res[K]["status"] = dev.get("status", (), np.int32)
+        ms, launches, sweeps, _ = dev.kernel_timing()
+        assert launches > 0 and sweeps >= launches
+        dev.close()
+    assert (res[1]["status"] == 0).all()
+    for k in res[1]:
+        assert np.array_equal(res[1][k], res[3][k]), k
+
+
 def _nlp_kkt_residual(m, N, X, U, x_meas):
     """Independent certificate for the nominal NLP (solver/nlp.py:158-217): dynamics defect, box violation, and the stationarity
     residual min over multipliers (nu free, lambda >= 0 on active bounds only) of |2 H y + J' nu + sum_active +-lambda|."""

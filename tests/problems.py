@@ -23,10 +23,16 @@ class Instance:
     pass
 
 
-def make_instance(model_name, seed=0, x0_amp=0.2, c_amp=1e-3):
+def make_instance(model_name, seed=0, x0_amp=0.2, c_amp=1e-3, N=None):
+    """N: horizon; default = the fixture's.  Other horizons reuse the fixture's stages cyclically (data only needs to be plausible)."""
     m = get_model(model_name)
     g = dict(np.load(os.path.join(GOLDEN, FIXTURE[model_name])))
-    N = int(g["N"])
+    N0 = int(g["N"])
+    if N is not None and N != N0:
+        idx = np.arange(N) % N0
+        g["A"], g["B"], g["U"] = g["A"][idx], g["B"][idx], g["U"][idx]
+        g["X"] = g["X"][np.arange(N + 1) % (N0 + 1)]
+    N = N0 if N is None else int(N)
     nx, nu, nz = m.nx, m.nu, m.nz
     rng = np.random.default_rng(1000 + seed)
     inst = Instance()

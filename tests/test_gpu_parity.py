@@ -76,6 +76,21 @@ def test_qp_vs_oracle(model, amps):
             assert np.allclose(y[b][: -m.nx][act], yo[: -m.nx][act], rtol=1e-5, atol=1e-6 * scale)
 
 
+@pytest.mark.parametrize("model,N", [("pendulum", 1), ("pendulum", 32), ("quadrotor", 7), ("rocket", 15)])
+def test_other_horizons_vs_oracle(model, N):
+    """Horizon edge cases: N = 1 (a single stage), the ABI's maximum N = 32, an odd horizon, and N = 15, the rocket script's own default
+    (expe/main_rocket_robust_closed_loop.py:63).  One RTI fast-SLS step (2 QPs + sweep) against the oracle."""
+    insts = [make_instance(model, s, 0.5, N=N) for s in range(2)]
+    out = run_gpu_fastsls(insts, rti_steps=1)
+    for b, inst in enumerate(insts):
+        ref = run_oracle_fastsls(inst, rti_steps=1)
+        assert bool(out["success"][b]) == bool(ref["success"])
+        assert out["primal_vec"].shape[1] == inst.m.nz * N + inst.m.nx
+        assert relerr(out["primal_vec"][b], ref["primal_vec"]) < 1e-6
+        assert relerr(out["backoff"][b], ref["backoff"]) < 1e-6
+        assert relerr(out["beta_f"][b], ref["beta_f"]) < 1e-6
+
+
 def test_qp_csc_boundary_matches_dense_boundary():
     """update_data_mat(P_x, A_x) in the reference's CSC order (qp_jit.py:671-698) == update_dynamics with dense blocks."""
     import scipy.sparse as sp

@@ -15,20 +15,55 @@ def disturbance_stream(seed, steps, nx):
     return np.stack([2.0 * rs.rand(nx) - 1.0 for _ in range(steps)])
 
 
-def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise=True, gather=True, solve_nominal=False):
+def _run_slice(model, N, seeds, steps, x0, device, noise, solve_nominal):
+    B = len(seeds)
+    W = np.stack([disturbance_stream(s, steps, model.nx) for s in seeds], axis=1) if noise else None   # (steps, B, nx)
+    cl = ClosedLoopMPC(model, N, B, device=device)
+    out = cl.run(np.tile(np.asarray(x0, dtype=float), (B, 1)), steps, W, solve_nominal=solve_nominal)
+    if cl.nlp_status is not None:
+        out.update(nlp_status=cl.nlp_status, nlp_iterations=cl.nlp_iterations)
+    cl.close()
+    return out
+
+
+def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise=True, gather=True, solve_nominal=False, slices=1):
+    """slices > 1: the rank's seeds are cut into that many independent slices, each with its own handle (HIP stream) and host thread
+    (as in fast_sls.SlicedDeviceBatch): results are bit-identical, the slices' solver tails overlap each other's bulk launches."""
+    import threading
     seeds = np.asarray(seeds)
     S = len(seeds)
     lo, hi = shard_range(S, rank, world)
     mine = seeds[lo:hi]
     B = len(mine)
-    W = np.stack([disturbance_stream(s, steps, model.nx) for s in mine], axis=1) if noise else None   # (steps, B, nx)
-    cl = ClosedLoopMPC(model, N, B, device=device)
-    out = cl.run(np.tile(np.asarray(x0, dtype=float), (B, 1)), steps, W, solve_nominal=solve_nominal)
-    nlp = None if cl.nlp_status is None else dict(nlp_status=cl.nlp_status, nlp_iterations=cl.nlp_iterations)
-    cl.close()
+    K = max(1, min(int(slices), B))
+    cuts = [(B * k // K, B * (k + 1) // K) for k in range(K)]
+    parts, err = [None] * K, []
+
+    def work(k):
+        try:
+            parts[k] = _run_slice(model, N, mine[cuts[k][0]:cuts[k][1]], steps, x0, device, noise, solve_nominal)
+        except Exception as e:
+            err.append(e)
+
+    if K == 1:
+        work(0)
+    else:
+        th = [threading.Thread(target=work, args=(k,)) for k in range(K)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    if err:
+        raise err[0]
+    out = {}
+    for key, v in parts[0].items():
+        if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == cuts[0][1] - cuts[0][0] and key not in ("t_jac", "t_qp", "t_riccati"):
+            out[key] = np.concatenate([p[key] for p in parts], axis=0)
+        elif key in ("t_qp", "t_riccati"):
+            out[key] = np.max(np.stack([p[key] for p in parts]), axis=0)      # slices run concurrently
+        else:
+            out[key] = v
     res = dict(seeds=mine, **out)
-    if nlp:
-        res.update(nlp)
     if gather and world > 1:
         import torch
         dev = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")

@@ -497,6 +497,21 @@ extern "C" int slsqp_get(slsqp_handle *h, const char *name, void *out, int loc) 
     return 0;
 }
 
+// Overwrite a named array (the reference's callers poke the QP's bounds between solves: QP.update_ubg, qp_jit.py:578-586, used by
+// SCP_SLS_jit.py:86-99).  Writable: ubg, lbg, q, nominal_x, nominal_u, x_meas.
+extern "C" int slsqp_set(slsqp_handle *h, const char *name, const void *src, int loc) {
+    hipSetDevice(h->dev);
+    static const char *ok[] = {"ubg", "lbg", "q", "nominal_x", "nominal_u", "x_meas"};
+    bool allowed = false;
+    for (const char *k : ok) allowed |= (strcmp(k, name) == 0);
+    auto it = h->named.find(name);
+    if (!allowed || it == h->named.end()) return fail(std::string("slsqp_set: not a writable array: ") + name);
+    const size_t bytes = it->second.second * (size_t)h->B;
+    HIPCHK(hipMemcpyAsync(it->second.first, src, bytes, loc == SLSQP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    return 0;
+}
+
 extern "C" int slsqp_reset(slsqp_handle *h) {
     hipSetDevice(h->dev);
     // reset_solver_to_zeros (fast_SLS_jit.py:424-442): eta/eta_f/iteration_number to zero, bounds and linear cost dropped.

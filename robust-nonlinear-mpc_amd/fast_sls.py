@@ -31,16 +31,71 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class _ModelView:
+    """What the path needs from the plant / LTV object, as numpy.  Accepts this package's ModelData as well as the reference's
+    `LTV(m, N)` (dyn/LTV.py:17-32: nx, nu, nw, ni, ni_f, G, Gf, gf and nothing else; G may be a casadi DM)."""
+
+    def __init__(self, model):
+        self.src = model
+        self.nx, self.nu, self.nw = int(model.nx), int(model.nu), int(model.nw)
+        self.nz = self.nx + self.nu
+        self.ni, self.ni_f = int(model.ni), int(model.ni_f)
+        self.G, self.Gf = _c(np.asarray(model.G, dtype=float)), _c(np.asarray(model.Gf, dtype=float))
+        self.gf = _c(np.asarray(model.gf, dtype=float)).ravel()
+        E = getattr(model, "E", None)            # LTV starts from all-ones blocks and gets E through update_dynamics_list
+        self.E = np.ones((self.nx, self.nw)) if E is None else _c(np.asarray(E, dtype=float))
+        self.model_id = getattr(model, "model_id", None)
+        g = getattr(model, "g", None)
+        self.g = None if g is None else _c(np.asarray(g, dtype=float)).ravel()
+
+    def __getattr__(self, k):                     # weights, reference points, ... of ModelData
+        return getattr(self.src, k)
+
+
+class _SolverForward:
+    """The attributes SCP_SLS and the closed-loop scripts touch on `fast_SLS.solver_forward` (the reference's QP object):
+    P_mat_csc (SCP_SLS_jit.py:389), ubg / update_ubg (:86-99, :521), verbose / export_standard_qp (expe/main_*:86-91)."""
+
+    def __init__(self, owner):
+        self._o = owner
+        self.verbose = False
+        self.export_standard_qp = False
+
+    @property
+    def P_mat_csc(self):
+        from scipy.sparse import block_diag, csc_matrix
+        o = self._o
+        return csc_matrix(block_diag([o.Q, o.R] * o.N + [o.Qf]))      # P = blkdiag(Q,R,...,Qf) (qp_jit.py:126-130); OSQP gets 2P
+
+    @property
+    def ubg(self):
+        u = self._o.get("ubg", (self._o.mb,))
+        return u[0] if self._o.B == 1 else u
+
+    @property
+    def lbg(self):
+        l = self._o.get("lbg", (self._o.mb,))
+        return l[0] if self._o.B == 1 else l
+
+    def update_ubg(self, ubg):
+        o = self._o
+        u = _c(np.asarray(ubg, dtype=float)).reshape(o.B, o.mb)
+        L.check(o.lib.slsqp_set(o.h, b"ubg", _ptr(u), L.HOST))
+
+
 class BatchedFastSLS:
     def __init__(self, N, Q, R, model, Qf, Q_reg=None, R_reg=None, Q_reg_f=None, batch=1, device=0):
         self.lib = L.load()
+        self.h = None
+        model = model if isinstance(model, _ModelView) else _ModelView(model)
         self.N, self.m, self.B = int(N), model, int(batch)
         nx, nu = model.nx, model.nu
         self.Q, self.R, self.Qf = _c(Q), _c(R), _c(Qf)
         # OCP defaults (solver/ocp.py:14-27)
-        self.Q_reg = _c(np.eye(nx) if Q_reg is None else Q_reg)
-        self.R_reg = _c(np.eye(nu) if R_reg is None else R_reg)
-        self.Q_reg_f = _c(np.eye(nx) if Q_reg_f is None else Q_reg_f)
+        self._Q_reg = _c(np.eye(nx) if Q_reg is None else Q_reg)
+        self._R_reg = _c(np.eye(nu) if R_reg is None else R_reg)
+        self._Q_reg_f = _c(np.eye(nx) if Q_reg_f is None else Q_reg_f)
+        self.solver_forward = _SolverForward(self)
         self.dims = L.Dims(nx, nu, model.nw, self.N, model.ni, model.ni_f)
         self.n = model.nz * self.N + nx
         self.mb = self.N * (nx + model.ni) + model.ni_f
@@ -59,13 +114,27 @@ class BatchedFastSLS:
         G, Gf, gf = _c(model.G), _c(model.Gf), _c(model.gf)
         L.check(self.lib.slsqp_set_constraints(self.h, _ptr(G), _ptr(Gf), _ptr(gf)))
         self._E = _c(np.stack([model.E] * (self.N + 1)))
-        if getattr(model, "model_id", None) is not None:
+        if model.model_id is not None and model.g is not None:
             g_raw = _c(model.g)
             L.check(self.lib.slsqp_set_model(self.h, int(model.model_id), _ptr(g_raw)))
             L.check(self.lib.slsqp_set_E(self.h, _ptr(self._E), L.HOST))
 
     def _push_costs(self):
-        L.check(self.lib.slsqp_set_costs(self.h, _ptr(self.Q), _ptr(self.R), _ptr(self.Qf), _ptr(self.Q_reg), _ptr(self.R_reg), _ptr(self.Q_reg_f)))
+        L.check(self.lib.slsqp_set_costs(self.h, _ptr(self.Q), _ptr(self.R), _ptr(self.Qf), _ptr(self._Q_reg), _ptr(self._R_reg), _ptr(self._Q_reg_f)))
+
+    # SCP_SLS assigns these after construction (`self.fast_SLS_solver.Q_reg = self.Q_reg`, SCP_SLS_jit.py:386-388): assignment takes effect
+    def _reg_prop(name):
+        def get(self):
+            return getattr(self, name)
+
+        def put(self, v):
+            setattr(self, name, _c(np.asarray(v, dtype=float)))
+            if getattr(self, "h", None):
+                self._push_costs()
+        return property(get, put)
+
+    Q_reg, R_reg, Q_reg_f = _reg_prop("_Q_reg"), _reg_prop("_R_reg"), _reg_prop("_Q_reg_f")
+    del _reg_prop
 
     def close(self):
         if getattr(self, "h", None):
@@ -83,8 +152,8 @@ class BatchedFastSLS:
         self.opts.rti_steps = 0 if (steps is None or steps <= 0) else int(steps)
 
     def set_regularisers(self, Q_reg, R_reg, Q_reg_f):
-        """SCP_SLS pokes .Q_reg/.R_reg/.Q_reg_f after construction (SCP_SLS_jit.py:386-388)."""
-        self.Q_reg, self.R_reg, self.Q_reg_f = _c(Q_reg), _c(R_reg), _c(Q_reg_f)
+        """All three at once (one push)."""
+        self._Q_reg, self._R_reg, self._Q_reg_f = _c(Q_reg), _c(R_reg), _c(Q_reg_f)
         self._push_costs()
 
     def update_dynamics_list(self, A, Bm, E=None, g=None, g_N=None, c=None):
@@ -108,6 +177,11 @@ class BatchedFastSLS:
         q = _c(q)
         assert q.shape == (self.B, self.n)
         L.check(self.lib.slsqp_update_linear_cost(self.h, _ptr(q), L.HOST))
+
+    def add_linear_cost(self, q):
+        """fast_SLS.add_linear_cost (fast_SLS_jit.py:578-579): q_lin += q."""
+        q = _c(q).reshape(self.B, self.n)
+        self.update_linear_cost(self.get("q", (self.n,)) + q)
 
     def reset_solver_to_zeros(self):
         L.check(self.lib.slsqp_reset(self.h))
@@ -225,6 +299,9 @@ class fast_SLS(BatchedFastSLS):
 
     def update_linear_cost(self, q_cost_lin):
         super().update_linear_cost(np.asarray(q_cost_lin, dtype=float).reshape(1, -1))
+
+    def add_linear_cost(self, q_cost_lin):
+        super().add_linear_cost(np.asarray(q_cost_lin, dtype=float).reshape(1, -1))
 
     def solve(self, x0):
         out = super().solve(np.asarray(x0, dtype=float).reshape(1, -1))

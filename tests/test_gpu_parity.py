@@ -298,6 +298,52 @@ def test_mixed_precision_matches_fp64_and_oracle(model, B):
     f.close()
 
 
+def test_drop_in_surface_with_a_reference_shaped_ltv_object():
+    """Level-1 switch: SCP_SLS builds `fast_SLS(N, Q, R, LTV(m, N), Qf)` from an object that only has what
+    dyn/LTV.py:17-32 copies from the plant, assigns `.Q_reg/.R_reg/.Q_reg_f` afterwards (SCP_SLS_jit.py:386-388), reads
+    `.solver_forward.P_mat_csc` (:389) and `.solver_forward.ubg` (:86, :521), calls `.solver_forward.update_ubg` (:99) and the scripts set
+    `.solver_forward.verbose / .export_standard_qp` (expe/main_rocket...:86-91).  All of that must work and mean the same."""
+    from robust_nonlinear_mpc_amd import fast_SLS
+    inst = make_instance("pendulum", 1, 0.5)
+    m, N = inst.m, inst.N
+
+    class LTVLike:                               # dyn/LTV.py:17-32
+        pass
+    ltv = LTVLike()
+    ltv.N, ltv.nx, ltv.nu, ltv.nw, ltv.G, ltv.ni, ltv.Gf, ltv.gf, ltv.ni_f = N, m.nx, m.nu, m.nw, m.G, m.ni, m.Gf, m.gf, m.ni_f
+
+    f = fast_SLS(N, m.Q, m.R, ltv, m.Qf)         # regularisers default to identity (ocp.py:14-27)
+    f.Q_reg, f.R_reg, f.Q_reg_f = m.Q_reg, m.R_reg, m.Q_reg_f
+    f.solver_forward.verbose = False
+    f.solver_forward.export_standard_qp = False
+    f.set_rti_steps(1)
+    P = f.solver_forward.P_mat_csc
+    Hd = np.concatenate([np.concatenate([np.diag(m.Q), np.diag(m.R)])] * N + [np.diag(m.Qf)])
+    assert P.shape == (f.n, f.n) and np.allclose(P.diagonal(), Hd) and abs(P - P.T).max() == 0
+    f.update_dynamics_list(list(inst.A), list(inst.B), list(inst.E), inst.g_list, list(inst.c))
+    f.update_linear_cost(0.5 * inst.q)
+    f.add_linear_cost(0.5 * inst.q)
+    out = f.solve(inst.x0_arg)
+    ref = run_oracle_fastsls(inst, rti_steps=1)
+    assert out["success"] and relerr(out["primal_vec"], ref["primal_vec"]) < 1e-6
+    assert relerr(out["backoff"], ref["backoff"]) < 1e-6          # needs the assigned regularisers, not the identity defaults
+    ubg = np.array(f.solver_forward.ubg, dtype=float).reshape(-1)   # the tightened bounds of the last step (SCP_SLS_jit.py:521)
+    assert ubg.shape == (f.mb,)
+    # update_ubg: closing the first input's box to a single point must pin that input in the next QP
+    f.update_dynamics_list(list(inst.A), list(inst.B), list(inst.E), inst.g_list, list(inst.c))
+    f.update_linear_cost(inst.q)
+    ub = np.array(f.solver_forward.ubg, dtype=float).reshape(-1)
+    SR = m.nx + m.ni
+    target = 0.25 * ub[m.nx + m.nx]                                  # inside the box of u_0
+    ub2 = ub.copy()
+    ub2[m.nx + m.nx] = target                                        # u_0 <= target
+    ub2[m.nx + m.nz + m.nx] = -target                                # -u_0 <= -target
+    f.solver_forward.update_ubg(ub2)
+    x, y, st, it, _ = f.qp_solve()
+    assert st[0] == 0 and abs(x[0, m.nx] - target) < 1e-8
+    f.close()
+
+
 def test_sliced_batch_is_bitwise_the_single_slice_result():
     """bench.py / Monte-Carlo runs cut a rank's batch into independent slices (own handle, stream and host thread each) that advance
     without lockstep.  An instance is always computed by one wavefront from its own data, so slicing must not change a single bit."""

@@ -298,6 +298,49 @@ def test_mixed_precision_matches_fp64_and_oracle(model, B):
     f.close()
 
 
+def test_osqp_generated_stand_in_module():
+    """Level-2 switch: the module-level singleton the reference drives as `osqp_generated`
+    (QP._cg_push_updates qp_jit.py:671-698, QP.solve :449-470): update_data_mat(P_x=, A_x=) -> 0, update_data_vec(q, l, u) -> 0,
+    solve() -> (x, y, status_code, iter, run_time) with status_code 0 = solved; data in the reference's frozen CSC order."""
+    import scipy.sparse as sp
+    from oracle import oracle as O
+    from robust_nonlinear_mpc_amd import osqp_generated as cg
+    inst = make_instance("pendulum", 2, 1.0)
+    m, N = inst.m, inst.N
+    nx, nu, nz, ni, nif = m.nx, m.nu, m.nz, m.ni, m.ni_f
+    n = nz * N + nx
+    # constraint matrix exactly as QP._assemble_structures lays it out (qp_jit.py:101-123, 178-186), dense A_k, B_k blocks
+    rows = []
+    for k in range(N):
+        r = np.zeros((nx, n)); r[:, k * nz:k * nz + nx] = inst.A[k]; r[:, k * nz + nx:(k + 1) * nz] = inst.B[k]; r[:, (k + 1) * nz:(k + 1) * nz + nx] = -np.eye(nx)
+        gk = np.zeros((ni, n)); gk[:, k * nz:(k + 1) * nz] = m.G
+        rows += [r, gk]
+    gf = np.zeros((nif, n)); gf[:, N * nz:] = m.Gf
+    pin = np.zeros((nx, n)); pin[:, :nx] = np.eye(nx)
+    Amat = np.vstack(rows + [gf, pin])
+    # frozen pattern: dense A_k, B_k (incl. zeros), the -I, G, Gf and pin entries
+    mask = (Amat != 0)
+    for k in range(N):
+        mask[k * (nx + ni):k * (nx + ni) + nx, k * nz:(k + 1) * nz] = True
+    A_csc = sp.csc_matrix((Amat[mask.nonzero()], mask.nonzero()), shape=Amat.shape)
+    A_csc.sort_indices()
+    Hd = np.concatenate([np.concatenate([np.diag(m.Q), np.diag(m.R)])] * N + [np.diag(m.Qf)])
+    P_ut = sp.triu(sp.diags(2.0 * Hd), format="csc")
+    l, u = qp1_bounds(inst)
+    assert cg.update_data_mat(P_x=P_ut.data, A_x=A_csc.data) == 0
+    assert cg.update_data_vec(inst.q, l, u) == 0
+    x, y, status_code, iters, run_time = cg.solve()
+    assert status_code == 0 and run_time > 0 and x.shape == (n,) and y.shape == (Amat.shape[0],)
+    xo, yo, info = O.qp_solve(oracle_dims(inst), inst.A, inst.B, m.G, m.Gf, m.Q, m.R, m.Qf, inst.q, l, u, O.tight_settings())
+    assert relerr(x, xo) < 1e-6
+    assert np.abs(Amat[-nx:] @ x - 0.5 * (l[-nx:] + u[-nx:])).max() < 1e-9          # x0 pin rows honoured
+    # second solve with new vectors only (the reference pushes vectors every solve)
+    assert cg.update_data_vec(0.5 * inst.q, l, u) == 0
+    x2 = cg.solve()[0]
+    assert relerr(x2, x) > 1e-4
+    cg.reset()
+
+
 def test_drop_in_surface_with_a_reference_shaped_ltv_object():
     """Level-1 switch: SCP_SLS builds `fast_SLS(N, Q, R, LTV(m, N), Qf)` from an object that only has what
     dyn/LTV.py:17-32 copies from the plant, assigns `.Q_reg/.R_reg/.Q_reg_f` afterwards (SCP_SLS_jit.py:386-388), reads

@@ -102,6 +102,11 @@ struct NeG {   // global-memory operands of the sweeps (this instance)
 //   optional (re)factorisation, block LDL':  D_k = Y_kk - O_k D_{k-1}^-1 O_k',  O_k = Y_{k,k-1} = -A_k diag(pi_x,k)
 //   (explicit symmetric inverses Dinv_k kept, written to HBM scratch),
 //   rhs b_k = E_k v - eflag * e_k, forward elimination t_k = b_k - O_k u_{k-1},  u_k = Dinv_k t_k  (u_k stored in W).
+// NE_MFMA (default 1): the factor sweep's products T = M1 Dinv and D_k = M1 A' + B diag(pi) B' - T M1' + diag run on the fp64 matrix core
+// for NX >= 13 (wla::gemm_mfma / build_Y_mfma); 0 = vector-ALU versions.
+#ifndef NE_MFMA
+#define NE_MFMA 1
+#endif
 #ifdef NE_STAMP
 #define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc_[i] += t_ - last_; last_ = t_; } while (0)
 #else
@@ -159,6 +164,10 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             wla::wsync();
             STAMP(1);
             if (k > 0) {   // T = M1 Dinv_{k-1}   (Dinv symmetric, so the NT product is the NN one)
+#if NE_MFMA
+                if constexpr (NX >= 13) wla::gemm_mfma<NX, NX, NX, false, false>(Lcur, NX, Lprev, NX, sL1, NX, lane);
+                else
+#endif
                 wla::gemm_nt_blk<NX, NX, NX, 3, 2>(Lcur, NX, Lprev, NX, sL1, NX, 1.0, lane);
                 wla::wsync();
             }
@@ -166,6 +175,10 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             // lower(D_k) = M1 A' + B diag(pi_u) B' + diag(pi_x,k+1) + delta - T M1'      (block LDL': D_k = Y_kk - O D_{k-1}^-1 O')
             // D_k is built where Dinv_{k-1} was (dead once T is formed: u_{k-1} is kept in sWp), inverted from there into M1's buffer
             double *sY = Lprev;
+#if NE_MFMA
+            if constexpr (NX >= 13) wla::build_Y_mfma<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
+            else
+#endif
             wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
             wla::wsync();
             STAMP(3);
@@ -1013,6 +1026,11 @@ __host__ __device__ constexpr int sweep_lds_doubles() {
     return 4 * NX * NX + 5 * NX * NU + NU * NU + (NX + NU) + 8;
 }
 
+// SWEEP_MFMA (default 1): the dense products of the sweep (A'S, y Acl, Acl Phi, B'S, x A, K Phi, A + B K) run on the fp64 matrix core for
+// NX >= 13 (wla::gemm_mfma: one 16x16 tile, the 17th row / column / k on the vector ALU beside it); 0 = vector-ALU GEMMs only.
+#ifndef SWEEP_MFMA
+#define SWEEP_MFMA 1
+#endif
 #ifndef SWEEP_WAVES_PER_SIMD
 #define SWEEP_WAVES_PER_SIMD 3
 #endif
@@ -1080,10 +1098,22 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
         if (lane < NZ) sC[lane] = rC;
         wla::wsync();
         if (k - 1 >= j) fetch(k - 1);
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NU, NX, NX, true, false>(sB, NU, sS, NX, sX, NX, lane);
+        else
+#endif
         wla::gemm_blk<NU, NX, NX, true, false, 1, 2, false>(sB, NU, sS, NX, sX, NX, 1.0, lane);   // x = B' S   (NU x NX)
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NX, NX, NX, true, false>(sA, NX, sS, NX, sYm, NX, lane);   // y = A' S on the fp64 matrix core
+        else
+#endif
         wla::gemm_blk<NX, NX, NX, true, false, 3, 2, false>(sA, NX, sS, NX, sYm, NX, 1.0, lane);  // y = A' S   (NX x NX)
         wla::wsync();
         wla::gemm<NU, NU, NX, false, false>(sX, NX, sB, NU, sH, NU, 1.0, 0.0, lane);  // H = x B
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NU, NX, NX, false, false>(sX, NX, sA, NX, sF, NX, lane);
+        else
+#endif
         wla::gemm_blk<NU, NX, NX, false, false, 1, 2, false>(sX, NX, sA, NX, sF, NX, 1.0, lane);  // F = x A
         wla::wsync();
         if (lane < NU) sH[lane * NU + lane] += sC[NX + lane];
@@ -1102,6 +1132,10 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
 #pragma unroll
         for (int o = lane; o < NU * NX; o += 64) Kg[o] = sK[o];
         // Acl = A + B K
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NX, NX, NU, false, false, true>(sB, NU, sK, NX, sAcl, NX, lane, sA, NX);
+        else
+#endif
 #pragma unroll
         for (int o = lane; o < NX * NX; o += 64) {
             const int i = o / NX, jj = o % NX;
@@ -1111,6 +1145,10 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
             sAcl[o] = s;
         }
         wla::wsync();
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NX, NX, NX, false, false>(sYm, NX, sAcl, NX, sSn, NX, lane);
+        else
+#endif
         wla::gemm_blk<NX, NX, NX, false, false, 3, 2, false>(sYm, NX, sAcl, NX, sSn, NX, 1.0, lane);  // y (A + B K)
         wla::wsync();
 #pragma unroll
@@ -1144,7 +1182,15 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
         for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) { sB[o] = rB[r]; sK[o] = rK[r]; } }
         wla::wsync();
         if (k + 1 < N) fetch2(k + 1);
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NU, NW, NX, false, false>(sK, NX, Pc, NW, sPu, NW, lane);
+        else
+#endif
         wla::gemm_blk<NU, NW, NX, false, false, 1, 2, false>(sK, NX, Pc, NW, sPu, NW, 1.0, lane);  // Phi_u = K Phi_x
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NX, NX, NU, false, false, true>(sB, NU, sK, NX, sAcl, NX, lane, sA, NX);
+        else
+#endif
 #pragma unroll
         for (int o = lane; o < NX * NX; o += 64) {
             const int i = o / NX, jj = o % NX;
@@ -1164,6 +1210,10 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
             double *bo = beta + ((size_t)k * N + j) * NI;
             bo[lane] = s; bo[NZ + lane] = s;
         }
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NX, NW, NX, false, false>(sAcl, NX, Pc, NW, Pn, NW, lane);        // Phi_{k+1} = Acl Phi_k
+        else
+#endif
         wla::gemm_blk<NX, NW, NX, false, false, 3, 2, false>(sAcl, NX, Pc, NW, Pn, NW, 1.0, lane);
         wla::wsync();
         double *t = Pc; Pc = Pn; Pn = t;

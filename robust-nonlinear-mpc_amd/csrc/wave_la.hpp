@@ -158,6 +158,52 @@ __device__ __forceinline__ void gemm_blk(const double *A, int lda, const double 
     }
 }
 
+// C(MxN) = op(A)(MxK) op(B)(KxN) for M, N, K <= 17 on the fp64 matrix core: the 16x16x16 core of the product is four
+// v_mfma_f64_16x16x4_f64 (lane l feeds A[l&15][k0 + (l>>4)] and B[k0 + (l>>4)][l&15]; its 4 results are rows (l>>4) + 4r, column l&15), the
+// 17th k adds a rank-1 term to those results, and the 17th row / column of the result (33 entries) are plain dot products on the
+// vector ALU, which runs beside the matrix pipe.  Needs all 64 lanes active.  Summation order differs from gemm_blk (last-bit effects).
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+// D (optional, MxN, leading dim ldd): C = D + op(A) op(B).
+template <int M, int N, int K, bool TA, bool TB, bool ADD = false>
+__device__ __forceinline__ void gemm_mfma(const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lane, const double *D = nullptr,
+                                          int ldd = 0) {
+    static_assert(M <= 17 && N <= 17 && K <= 17, "one 16x16 tile plus one border row / column / k");
+    constexpr int MC = M < 16 ? M : 16, NC = N < 16 ? N : 16, KC = K < 16 ? K : 16;
+    const int li = lane & 15, lk = lane >> 4;
+    auto a_at = [&](int i, int k) -> double { return TA ? A[k * lda + i] : A[i * lda + k]; };
+    auto b_at = [&](int k, int j) -> double { return TB ? B[j * ldb + k] : B[k * ldb + j]; };
+    const int ia = min(li, MC - 1), jb = min(li, NC - 1);
+    mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (ADD) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = D[min(lk + 4 * r, MC - 1) * ldd + jb];
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < KC; k0 += 4) {
+        const int k = k0 + lk, kc = min(k, KC - 1);
+        const double av = a_at(ia, kc), bv = b_at(kc, jb);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((li < MC && k < KC) ? av : 0.0, (li < NC && k < KC) ? bv : 0.0, acc, 0, 0, 0);
+    }
+    if constexpr (K == 17) {
+        const double b16 = b_at(16, jb);
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = fma(a_at(min(lk + 4 * r, MC - 1), 16), b16, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int i = lk + 4 * r; if (i < MC && li < NC) C[i * ldc + li] = acc[r]; }
+    if constexpr (M == 17 || N == 17) {
+        constexpr int NROW = (M == 17) ? N : 0, NCOL = (N == 17) ? MC : 0;
+        if (lane < NROW + NCOL) {
+            const bool isrow = lane < NROW;
+            const int i = isrow ? 16 : lane - NROW, j = isrow ? lane : 16;
+            double s = ADD ? D[i * ldd + j] : 0.0;
+#pragma unroll
+            for (int k = 0; k < K; k++) s = fma(a_at(i, k), b_at(k, j), s);
+            C[i * ldc + j] = s;
+        }
+    }
+}
+
 // Lower triangle (i >= j) of  Y = M1 A' + B diag(piu) B' - T M1' + diag(d) ,  all NX x NX (B: NX x NU), 2x2 blocks, one pass.
 // useT = false drops the T term.  Only the lower triangle of Y is written (the Cholesky reads nothing else).
 template <int NX, int NU, typename R>
@@ -197,6 +243,67 @@ __device__ __forceinline__ void build_Y_lower(const R *M1, const R *A, const R *
             Y[(i0 + 1) * NX + j0] = a10;
             if (j0 + 1 < NX) Y[(i0 + 1) * NX + j0 + 1] = a11;
         }
+    }
+}
+
+// build_Y_lower on the fp64 matrix core (NX in 13..17, NU <= 4): the three products accumulate in one 16x16 tile (9 MFMAs), the 17th k is a
+// rank-1 term on the results, and row 16 of the result (the only border entries in the lower triangle) is three partial dot products per
+// entry on 51 lanes, summed through the crossbar.  Writes the lower triangle of the core and the whole last row.
+template <int NX, int NU>
+__device__ __forceinline__ void build_Y_mfma(const double *M1, const double *A, const double *B, const double *piu, const double *Tm, bool useT,
+                                             const double *d, double delta, double *Y, int lane) {
+    static_assert(NX >= 5 && NX <= 17 && NU <= 4, "one 16x16 tile");
+    constexpr int MC = NX < 16 ? NX : 16;
+    const int li = lane & 15, lk = lane >> 4, lc = min(li, MC - 1);
+    mfma_d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int i = lk + 4 * r; acc[r] = (i == li && i < MC) ? d[min(i, NX - 1)] + delta : 0.0; }
+#pragma unroll
+    for (int k0 = 0; k0 < MC; k0 += 4) {
+        const int k = k0 + lk, kc = min(k, MC - 1);
+        const bool ok = (li < MC) && (k < MC);
+        const double m1 = M1[lc * NX + kc], av = A[lc * NX + kc];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? m1 : 0.0, ok ? av : 0.0, acc, 0, 0, 0);              // M1 A'
+        if (useT) {
+            const double tv = Tm[lc * NX + kc];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? -tv : 0.0, ok ? m1 : 0.0, acc, 0, 0, 0);         // - T M1'
+        }
+    }
+    {
+        const int u = min(lk, NU - 1);
+        const bool ok = (li < MC) && (lk < NU);
+        const double bv = B[lc * NU + u];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? bv * piu[u] : 0.0, ok ? bv : 0.0, acc, 0, 0, 0);     // B diag(piu) B'
+    }
+    if constexpr (NX == 17) {
+        const double a16 = A[lc * NX + 16], m16 = M1[lc * NX + 16];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = lk + 4 * r;
+            acc[r] = fma(M1[i * NX + 16], a16, acc[r]);
+            if (useT) acc[r] = fma(-Tm[i * NX + 16], m16, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int i = lk + 4 * r; if (i < MC && li <= i) Y[i * NX + li] = acc[r]; }
+    if constexpr (NX == 17) {
+        const int g = lane / 17, j = lane % 17;
+        double v = 0.0;
+        if (g == 0) {
+#pragma unroll
+            for (int k = 0; k < NX; k++) v = fma(M1[16 * NX + k], A[j * NX + k], v);
+        } else if (g == 1) {
+            if (useT) {
+#pragma unroll
+                for (int k = 0; k < NX; k++) v = fma(-Tm[16 * NX + k], M1[j * NX + k], v);
+            }
+        } else if (g == 2) {
+#pragma unroll
+            for (int u = 0; u < NU; u++) v = fma(B[16 * NU + u] * piu[u], B[j * NU + u], v);
+            if (j == 16) v += d[16] + delta;
+        }
+        const double s = v + __shfl(v, lane + 17) + __shfl(v, lane + 34);
+        if (lane < 17) Y[16 * NX + lane] = s;
     }
 }
 

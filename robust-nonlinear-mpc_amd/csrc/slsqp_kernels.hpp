@@ -27,6 +27,12 @@ constexpr int ST_INIT = -1;
 #define QP_WAVES_PER_SIMD 2
 #endif
 
+// NE_MFMA (default 1): the factor sweep's products T = M1 Dinv and D_k = M1 A' + B diag(pi) B' - T M1' + diag run on the fp64 matrix core
+// for NX >= 13 (wla::gemm_mfma / build_Y_mfma); 0 = vector-ALU versions.
+#ifndef NE_MFMA
+#define NE_MFMA 1
+#endif
+
 struct Costs {  // batch-constant diagonal weights (device pointers)
     const double *Qd, *Rd, *Qfd;        // diag of Q, R, Qf (P = 2*blkdiag)
     const double *Qregd, *Rregd, *Qregfd;
@@ -77,12 +83,13 @@ struct QpArgs {
     double early_ctol;        // tolerance (relative to max(1,|q|inf)) of the look at the un-refined polish solve: its accuracy class
 };
 
-// LDS layout of one QP wave: 4 NX x NX buffers (A_k | T = M1 Dinv_{k-1} | Dinv_{k-1}, then D_k | M1 -> Dinv_k; the last two rotate),
+// LDS layout of one QP wave: NX x NX buffers A_k | [T = M1 Dinv_{k-1}, vector-ALU path only] | Dinv_{k-1}, then T, then D_k | M1 -> Dinv_k (the last two rotate),
 // B_k, and a handful of stage vectors.  Everything of size n (IPM vectors) lives in an HBM/L2 workspace.
 template <int NX, int NU>
 struct QpLds {
     static constexpr int NZ = NX + NU, MM = NX * NX;
-    static constexpr int oA = 0, oL1 = MM, oP = 2 * MM, oQ = 3 * MM, oB = 4 * MM, oPiS = oB + NX * NU, oVS = oPiS + NZ + NX,
+    static constexpr bool MFMA = (NE_MFMA != 0) && NX >= 13;   // then T and D_k are built in place in the Dinv_{k-1} buffer: 3 NX^2 buffers
+    static constexpr int oA = 0, oL1 = MM, oP = MFMA ? MM : 2 * MM, oQ = oP + MM, oB = oQ + MM, oPiS = oB + NX * NU, oVS = oPiS + NZ + NX,
                          oWp = oVS + NZ + NX, oT1 = oWp + NX, oT2 = oT1 + NX, oT3 = oT2 + NX, TOTAL = oT3 + NX + 1;
 };
 template <int NX, int NU>
@@ -102,11 +109,6 @@ struct NeG {   // global-memory operands of the sweeps (this instance)
 //   optional (re)factorisation, block LDL':  D_k = Y_kk - O_k D_{k-1}^-1 O_k',  O_k = Y_{k,k-1} = -A_k diag(pi_x,k)
 //   (explicit symmetric inverses Dinv_k kept, written to HBM scratch),
 //   rhs b_k = E_k v - eflag * e_k, forward elimination t_k = b_k - O_k u_{k-1},  u_k = Dinv_k t_k  (u_k stored in W).
-// NE_MFMA (default 1): the factor sweep's products T = M1 Dinv and D_k = M1 A' + B diag(pi) B' - T M1' + diag run on the fp64 matrix core
-// for NX >= 13 (wla::gemm_mfma / build_Y_mfma); 0 = vector-ALU versions.
-#ifndef NE_MFMA
-#define NE_MFMA 1
-#endif
 #ifdef NE_STAMP
 #define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc_[i] += t_ - last_; last_ = t_; } while (0)
 #else
@@ -164,22 +166,16 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             wla::wsync();
             STAMP(1);
             if (k > 0) {   // T = M1 Dinv_{k-1}   (Dinv symmetric, so the NT product is the NN one)
-#if NE_MFMA
-                if constexpr (NX >= 13) wla::gemm_mfma<NX, NX, NX, false, false>(Lcur, NX, Lprev, NX, sL1, NX, lane);
-                else
-#endif
-                wla::gemm_nt_blk<NX, NX, NX, 3, 2>(Lcur, NX, Lprev, NX, sL1, NX, 1.0, lane);
+                if constexpr (Ld::MFMA) wla::gemm_mfma<NX, NX, NX, false, false>(Lcur, NX, Lprev, NX, Lprev, NX, lane);   // in place: T replaces Dinv_{k-1}
+                else wla::gemm_nt_blk<NX, NX, NX, 3, 2>(Lcur, NX, Lprev, NX, sL1, NX, 1.0, lane);
                 wla::wsync();
             }
             STAMP(2);
             // lower(D_k) = M1 A' + B diag(pi_u) B' + diag(pi_x,k+1) + delta - T M1'      (block LDL': D_k = Y_kk - O D_{k-1}^-1 O')
             // D_k is built where Dinv_{k-1} was (dead once T is formed: u_{k-1} is kept in sWp), inverted from there into M1's buffer
             double *sY = Lprev;
-#if NE_MFMA
-            if constexpr (NX >= 13) wla::build_Y_mfma<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
-            else
-#endif
-            wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
+            if constexpr (Ld::MFMA) wla::build_Y_mfma<NX, NU>(Lcur, sA, sB, sPiS + NX, Lprev, k > 0, sPiS + NZ, delta, sY, lane);   // in place over T
+            else wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
             wla::wsync();
             STAMP(3);
             fail |= wla::spd_inv_gj<NX>(sY, NX, Lcur, NX, (double *)nullptr, lane);

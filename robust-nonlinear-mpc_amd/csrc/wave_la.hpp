@@ -189,18 +189,25 @@ __device__ __forceinline__ void gemm_mfma(const double *A, int lda, const double
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[r] = fma(a_at(min(lk + 4 * r, MC - 1), 16), b16, acc[r]);
     }
+    // every load (core, rank-1, border) is issued before the first store, so C may be A or B itself: the LDS operations of the one wave
+    // of the workgroup execute in program order
+    constexpr int NROW = (M == 17) ? N : 0, NCOL = (N == 17) ? MC : 0;
+    double sb = 0.0;
+    int ib = 0, jb2 = 0;
+    if constexpr (M == 17 || N == 17) {
+        const bool isrow = lane < NROW;
+        ib = isrow ? 16 : min(lane - NROW, MC - 1); jb2 = isrow ? min(lane, N - 1) : 16;
+        if (lane < NROW + NCOL) {
+            sb = ADD ? D[ib * ldd + jb2] : 0.0;
+#pragma unroll
+            for (int k = 0; k < K; k++) sb = fma(a_at(ib, k), b_at(k, jb2), sb);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int i = lk + 4 * r; if (i < MC && li < NC) C[i * ldc + li] = acc[r]; }
     if constexpr (M == 17 || N == 17) {
-        constexpr int NROW = (M == 17) ? N : 0, NCOL = (N == 17) ? MC : 0;
-        if (lane < NROW + NCOL) {
-            const bool isrow = lane < NROW;
-            const int i = isrow ? 16 : lane - NROW, j = isrow ? lane : 16;
-            double s = ADD ? D[i * ldd + j] : 0.0;
-#pragma unroll
-            for (int k = 0; k < K; k++) s = fma(a_at(i, k), b_at(k, j), s);
-            C[i * ldc + j] = s;
-        }
+        if (lane < NROW + NCOL) C[ib * ldc + jb2] = sb;
     }
 }
 
@@ -284,8 +291,7 @@ __device__ __forceinline__ void build_Y_mfma(const double *M1, const double *A, 
             if (useT) acc[r] = fma(-Tm[i * NX + 16], m16, acc[r]);
         }
     }
-#pragma unroll
-    for (int r = 0; r < 4; r++) { const int i = lk + 4 * r; if (i < MC && li <= i) Y[i * NX + li] = acc[r]; }
+    double srow = 0.0;      // row 16 of the result, computed before anything is stored: Y may be Tm's (or M1's) buffer
     if constexpr (NX == 17) {
         const int g = lane / 17, j = lane % 17;
         double v = 0.0;
@@ -302,8 +308,13 @@ __device__ __forceinline__ void build_Y_mfma(const double *M1, const double *A, 
             for (int u = 0; u < NU; u++) v = fma(B[16 * NU + u] * piu[u], B[j * NU + u], v);
             if (j == 16) v += d[16] + delta;
         }
-        const double s = v + __shfl(v, lane + 17) + __shfl(v, lane + 34);
-        if (lane < 17) Y[16 * NX + lane] = s;
+        srow = v + __shfl(v, lane + 17) + __shfl(v, lane + 34);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int i = lk + 4 * r; if (i < MC && li <= i) Y[i * NX + li] = acc[r]; }
+    if constexpr (NX == 17) {
+        if (lane < 17) Y[16 * NX + lane] = srow;
     }
 }
 

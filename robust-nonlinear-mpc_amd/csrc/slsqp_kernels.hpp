@@ -186,26 +186,15 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             STAMP(5);
         }
         // rhs b = A v_x + B v_u - v_x,k+1 - eflag e_k  (+ A (pi_x,k .* Linv_{k-1}' w_{k-1}))
-        double b = 0.0;
-        if (lane < NX) {
-            b = -sVS[NZ + lane] - eflag * ek;
-#pragma unroll
-            for (int m = 0; m < NX; m++) b = fma(sA[lane * NX + m], sVS[m], b);
-#pragma unroll
-            for (int m = 0; m < NU; m++) b = fma(sB[lane * NU + m], sVS[NX + m], b);
-        }
-        if (k > 0) {   // t_k = b_k - O_k u_{k-1} = b_k + A_k (pi_x,k .* u_{k-1}),  u_{k-1} = Dinv_{k-1} t_{k-1} (kept in sWp)
-            if (lane < NX) sT1[lane] = sWp[lane] * sPiS[lane];
-            wla::wsync();
-            if (lane < NX) {
-#pragma unroll
-                for (int m = 0; m < NX; m++) b = fma(sA[lane * NX + m], sT1[m], b);
-            }
-        }
+        // t_k = A (v_x + pi_x,k .* u_{k-1}) + B v_u - v_x,k+1 - eflag e_k   (u_{k-1} = Dinv_{k-1} t_{k-1} kept in sWp; the second term is -O_k u_{k-1})
+        if (lane < NX) sT1[lane] = sVS[lane] + ((k > 0) ? sWp[lane] * sPiS[lane] : 0.0);
+        wla::wsync();
+        double b = wla::matvec_split3<NX, NX, false>(sA, NX, sT1, lane) + wla::matvec_split3<NX, NU, false>(sB, NU, sVS + NX, lane);
+        if (lane < NX) b += -sVS[NZ + lane] - eflag * ek; else b = 0.0;
         if (lane < NX) sT2[lane] = b;
         bmax = fmax(bmax, fabs(b));
         wla::wsync();
-        const double w = wla::matvec_row<NX, NX, false>(Lcur, NX, sT2, lane);   // u_k = Dinv_k t_k
+        const double w = wla::matvec_split3<NX, NX, false>(Lcur, NX, sT2, lane);   // u_k = Dinv_k t_k
         wla::wsync();
         if (lane < NX) { sWp[lane] = w; g.W[k * NX + lane] = w; }
         double *t = Lcur; Lcur = Lprev; Lprev = t;
@@ -231,32 +220,34 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
     double *sT1 = sm + Ld::oT1, *sT2 = sm + Ld::oT2, *sT3 = sm + Ld::oT3;
     if (lane < NX) sT3[lane] = 0.0;  // A_{k+1}' nu_{k+1}
     wla::wsync();
+    // the sweep is bound by the latency of the stage loads (A_k, B_k, Dinv_k stream through once, 2 kflop per stage): two stages are
+    // kept in flight in two register sets
     constexpr int RA = (MM + 63) / 64, RB = (NX * NU + 63) / 64;
-    double rA[RA], rB[RB], rL[RA], rPi = 0.0, rW = 0.0;
-    auto prefetch = [&](int k) {
+    struct StageRegs { double A[RA], L[RA], B[RB], Pi, W; };
+    StageRegs r0, r1;
+    auto load = [&](int k, StageRegs &r) {
         const double *Ak = g.A + (size_t)k * MM, *Bk = g.Bm + (size_t)k * NX * NU, *Lg = g.Linv + (size_t)k * MM;
 #pragma unroll
-        for (int r = 0; r < RA; r++) { const int o = min(r * 64 + lane, MM - 1); rA[r] = Ak[o]; rL[r] = Lg[o]; }
+        for (int q = 0; q < RA; q++) { const int o = min(q * 64 + lane, MM - 1); r.A[q] = Ak[o]; r.L[q] = Lg[o]; }
 #pragma unroll
-        for (int r = 0; r < RB; r++) rB[r] = Bk[min(r * 64 + lane, NX * NU - 1)];
+        for (int q = 0; q < RB; q++) r.B[q] = Bk[min(q * 64 + lane, NX * NU - 1)];
         const int lx = min(lane, NX - 1);
-        rPi = g.PI[(k + 1) * NZ + lx]; rW = g.W[k * NX + lx];
+        r.Pi = g.PI[(k + 1) * NZ + lx]; r.W = g.W[k * NX + lx];
     };
-    prefetch(g.N - 1);
-    for (int k = g.N - 1; k >= 0; k--) {
+    auto stage = [&](int k, StageRegs &r) {
 #pragma unroll
-        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < MM) { sA[o] = rA[r]; sLa[o] = rL[r]; } }
+        for (int q = 0; q < RA; q++) { const int o = q * 64 + lane; if (o < MM) { sA[o] = r.A[q]; sLa[o] = r.L[q]; } }
 #pragma unroll
-        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) sB[o] = rB[r]; }
-        if (lane < NX) { sPiS[lane] = rPi; sWp[lane] = rW; }
+        for (int q = 0; q < RB; q++) { const int o = q * 64 + lane; if (o < NX * NU) sB[o] = r.B[q]; }
+        if (lane < NX) { sPiS[lane] = r.Pi; sWp[lane] = r.W; }
         wla::wsync();
         STAMP(0);
-        if (k > 0) prefetch(k - 1);
+        if (k >= 2) load(k - 2, r);
         STAMP(1);
         if (lane < NX) sT1[lane] = sPiS[lane] * sT3[lane];
         wla::wsync();
         // nu_k = u_k - Dinv_k O_{k+1}' nu_{k+1} = u_k + Dinv_k (pi_x,k+1 .* A_{k+1}' nu_{k+1})
-        const double nu = sWp[lane < NX ? lane : 0] + wla::matvec_row<NX, NX, false>(sLa, NX, sT1, lane);
+        const double nu = sWp[lane < NX ? lane : 0] + wla::matvec_split3<NX, NX, false>(sLa, NX, sT1, lane);
         wla::wsync();
         STAMP(2);
         if (lane < NX) {
@@ -265,13 +256,19 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
             sT2[lane] = nu;
         }
         wla::wsync();
-        const double ga = wla::matvec_row<NX, NX, true>(sA, NX, sT2, lane);
-        const double gb = wla::matvec_row<NU, NX, true>(sB, NU, sT2, lane);
+        const double ga = wla::matvec_split3<NX, NX, true>(sA, NX, sT2, lane);
+        const double gb = wla::matvec_split3<NU, NX, true>(sB, NU, sT2, lane);
         wla::wsync();
         if (lane < NX) sT3[lane] = ga;
         if (lane < NU) g.G[k * NZ + NX + lane] = gb;
         wla::wsync();
         STAMP(3);
+    };
+    load(g.N - 1, r0);
+    if (g.N >= 2) load(g.N - 2, r1);
+    for (int k = g.N - 1; k >= 0; k -= 2) {
+        stage(k, r0);
+        if (k >= 1) stage(k - 1, r1);
     }
     if (lane < NX) g.G[lane] = sT3[lane];
 #ifdef NE_STAMP
@@ -372,7 +369,7 @@ __device__ __forceinline__ int ne_forward_mx(double *smd, const NeG<NX, NU> g, b
         if (lane < NX) fT[lane] = (float)b;
         bmax = fmax(bmax, fabs(b));
         wla::wsync();
-        const double w = (double)wla::matvec_row<NX, NX, false>(Lcur, NX, fT, lane);   // u_k = Dinv_k t_k  (fp32)
+        const double w = (double)wla::matvec_split3<NX, NX, false>(Lcur, NX, fT, lane);   // u_k = Dinv_k t_k  (fp32)
         wla::wsync();
         if (lane < NX) { sWp[lane] = w; g.W[k * NX + lane] = w; }
         float *t = Lcur; Lcur = Lprev; Lprev = t;
@@ -416,7 +413,7 @@ __device__ __forceinline__ void ne_backward_mx(double *smd, const NeG<NX, NU> g,
         if (k > 0) prefetch(k - 1);
         if (lane < NX) fT[lane] = (float)(sPiS[lane] * sT3[lane]);
         wla::wsync();
-        const double nu = sWp[lane < NX ? lane : 0] + (double)wla::matvec_row<NX, NX, false>(sLa, NX, fT, lane);
+        const double nu = sWp[lane < NX ? lane : 0] + (double)wla::matvec_split3<NX, NX, false>(sLa, NX, fT, lane);
         wla::wsync();
         if (lane < NX) {
             g.W[k * NX + lane] = nu;
@@ -424,8 +421,8 @@ __device__ __forceinline__ void ne_backward_mx(double *smd, const NeG<NX, NU> g,
             sT2[lane] = nu;
         }
         wla::wsync();
-        const double ga = wla::matvec_row<NX, NX, true>(sA, NX, sT2, lane);     // E' nu in fp64: consistent with the stored nu
-        const double gb = wla::matvec_row<NU, NX, true>(sB, NU, sT2, lane);
+        const double ga = wla::matvec_split3<NX, NX, true>(sA, NX, sT2, lane);     // E' nu in fp64: consistent with the stored nu
+        const double gb = wla::matvec_split3<NU, NX, true>(sB, NU, sT2, lane);
         wla::wsync();
         if (lane < NX) sT3[lane] = ga;
         if (lane < NU) g.G[k * NZ + NX + lane] = gb;
@@ -1105,7 +1102,17 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
 #endif
         wla::gemm_blk<NX, NX, NX, true, false, 3, 2, false>(sA, NX, sS, NX, sYm, NX, 1.0, lane);  // y = A' S   (NX x NX)
         wla::wsync();
-        wla::gemm<NU, NU, NX, false, false>(sX, NX, sB, NU, sH, NU, 1.0, 0.0, lane);  // H = x B
+        {   // H = x B (NU x NU), the sum over k split over three lane groups (lane = entry + NU^2 g)
+            constexpr int NH = NU * NU;
+            const int g3 = lane / NH, o = lane - g3 * NH, hi = o / NU, hj = o % NU;
+            double hs = 0.0;
+            if (g3 < 3) {
+#pragma unroll
+                for (int q = 0; q < (NX + 2) / 3; q++) { const int kk = 3 * q + g3; if (kk < NX) hs = fma(sX[hi * NX + kk], sB[kk * NU + hj], hs); }
+            }
+            hs = hs + __shfl(hs, lane + NH) + __shfl(hs, lane + 2 * NH);
+            if (lane < NH) sH[lane] = hs;
+        }
 #if SWEEP_MFMA
         if constexpr (NX >= 13) wla::gemm_mfma<NU, NX, NX, false, false>(sX, NX, sA, NX, sF, NX, lane);
         else
@@ -1197,14 +1204,20 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
         }
         wla::wsync();
         // beta[k,j,i] = max(|| row i of [Phi_x;Phi_u] ||^2, eps), rows i and NZ+i of G=[I;-I] coincide
-        if (lane < NZ) {
-            const double *row = (lane < NX) ? Pc + lane * NW : sPu + (lane - NX) * NW;
+        {   // row norms, the sum over w split over three lane groups (lane = row + NZ g)
+            const int g3 = lane / NZ, rw = lane - g3 * NZ;
+            const double *row = (rw < NX) ? Pc + rw * NW : sPu + (rw - NX) * NW;
             double s = 0.0;
+            if (g3 < 3) {
 #pragma unroll
-            for (int w = 0; w < NW; w++) s = fma(row[w], row[w], s);
-            s = fmax(s, a.eps);
-            double *bo = beta + ((size_t)k * N + j) * NI;
-            bo[lane] = s; bo[NZ + lane] = s;
+                for (int q = 0; q < (NW + 2) / 3; q++) { const int w = 3 * q + g3; if (w < NW) s = fma(row[w], row[w], s); }
+            }
+            s = s + __shfl(s, lane + NZ) + __shfl(s, lane + 2 * NZ);
+            if (lane < NZ) {
+                s = fmax(s, a.eps);
+                double *bo = beta + ((size_t)k * N + j) * NI;
+                bo[lane] = s; bo[NZ + lane] = s;
+            }
         }
 #if SWEEP_MFMA
         if constexpr (NX >= 13) wla::gemm_mfma<NX, NW, NX, false, false>(sAcl, NX, Pc, NW, Pn, NW, lane);        // Phi_{k+1} = Acl Phi_k

@@ -329,6 +329,23 @@ __device__ __forceinline__ T matvec_row(const T *A, int lda, const T *x, int lan
     return s;
 }
 
+// y(M) = op(A)(MxK) x(K) with the sum over k split three ways across lane groups (lane = i + M g, g = 0..2) and combined through the
+// crossbar: a dependent chain of ceil(K/3) FMAs instead of K, and a third of the LDS reads per lane.  Valid in lanes < M.
+template <int M, int K, bool TA, typename T>
+__device__ __forceinline__ T matvec_split3(const T *A, int lda, const T *x, int lane) {
+    static_assert(3 * M <= 64, "three lane groups");
+    const int g = lane / M, i = lane - g * M;
+    T s = T(0);
+    if (g < 3) {
+#pragma unroll
+        for (int q = 0; q < (K + 2) / 3; q++) {
+            const int k = 3 * q + g;
+            if (k < K) s = fma(TA ? A[k * lda + i] : A[i * lda + k], x[k], s);
+        }
+    }
+    return s + __shfl(s, lane + M) + __shfl(s, lane + 2 * M);
+}
+
 // v_rcp_f64 / v_rsq_f64 seeds + two Newton steps: ~1 ulp, a dependent chain of ~8 instructions instead of the ~30 of the
 // correctly rounded division / sqrt sequences (the factorisation below is latency-bound on exactly these chains).
 __device__ __forceinline__ double fast_rcp(double x) {

@@ -160,13 +160,15 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
         STAMP(0);
         if (k + 1 < g.N) prefetch(k + 1);
         if (factor) {
-            // M1 = A diag(pi_x,k) (into Lcur's buffer, dead until the inverse is written)
+            // M1 = A diag(pi_x,k) (into Lcur's buffer, dead until the inverse is written); the MFMA path scales its operands on the fly
+            if constexpr (!Ld::MFMA) {
 #pragma unroll
-            for (int o = lane; o < MM; o += 64) Lcur[o] = (k > 0) ? sA[o] * sPiS[o % NX] : 0.0;
-            wla::wsync();
+                for (int o = lane; o < MM; o += 64) Lcur[o] = (k > 0) ? sA[o] * sPiS[o % NX] : 0.0;
+                wla::wsync();
+            }
             STAMP(1);
             if (k > 0) {   // T = M1 Dinv_{k-1}   (Dinv symmetric, so the NT product is the NN one)
-                if constexpr (Ld::MFMA) wla::gemm_mfma<NX, NX, NX, false, false>(Lcur, NX, Lprev, NX, Lprev, NX, lane);   // in place: T replaces Dinv_{k-1}
+                if constexpr (Ld::MFMA) wla::gemm_mfma<NX, NX, NX, false, false, false, true>(sA, NX, Lprev, NX, Lprev, NX, lane, nullptr, 0, sPiS);   // in place: T replaces Dinv_{k-1}
                 else wla::gemm_nt_blk<NX, NX, NX, 3, 2>(Lcur, NX, Lprev, NX, sL1, NX, 1.0, lane);
                 wla::wsync();
             }
@@ -174,7 +176,7 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             // lower(D_k) = M1 A' + B diag(pi_u) B' + diag(pi_x,k+1) + delta - T M1'      (block LDL': D_k = Y_kk - O D_{k-1}^-1 O')
             // D_k is built where Dinv_{k-1} was (dead once T is formed: u_{k-1} is kept in sWp), inverted from there into M1's buffer
             double *sY = Lprev;
-            if constexpr (Ld::MFMA) wla::build_Y_mfma<NX, NU>(Lcur, sA, sB, sPiS + NX, Lprev, k > 0, sPiS + NZ, delta, sY, lane);   // in place over T
+            if constexpr (Ld::MFMA) wla::build_Y_mfma<NX, NU>(sA, sPiS, sB, sPiS + NX, Lprev, k > 0, sPiS + NZ, delta, sY, lane);   // in place over T
             else wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
             wla::wsync();
             STAMP(3);

@@ -171,13 +171,14 @@ __device__ __forceinline__ void gemm_blk(const double *A, int lda, const double 
 // vector ALU, which runs beside the matrix pipe.  Needs all 64 lanes active.  Summation order differs from gemm_blk (last-bit effects).
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 // D (optional, MxN, leading dim ldd): C = D + op(A) op(B).
-template <int M, int N, int K, bool TA, bool TB, bool ADD = false>
+// sk (optional, K): op(A) is used as op(A) diag(sk).
+template <int M, int N, int K, bool TA, bool TB, bool ADD = false, bool SCALEK = false>
 __device__ __forceinline__ void gemm_mfma(const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lane, const double *D = nullptr,
-                                          int ldd = 0) {
+                                          int ldd = 0, const double *sk = nullptr) {
     static_assert(M <= 17 && N <= 17 && K <= 17, "one 16x16 tile plus one border row / column / k");
     constexpr int MC = M < 16 ? M : 16, NC = N < 16 ? N : 16, KC = K < 16 ? K : 16;
     const int li = lane & 15, lk = lane >> 4;
-    auto a_at = [&](int i, int k) -> double { return TA ? A[k * lda + i] : A[i * lda + k]; };
+    auto a_at = [&](int i, int k) -> double { const double v = TA ? A[k * lda + i] : A[i * lda + k]; return SCALEK ? v * sk[k] : v; };
     auto b_at = [&](int k, int j) -> double { return TB ? B[j * ldb + k] : B[k * ldb + j]; };
     const int ia = min(li, MC - 1), jb = min(li, NC - 1);
     mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -260,11 +261,12 @@ __device__ __forceinline__ void build_Y_lower(const R *M1, const R *A, const R *
     }
 }
 
-// build_Y_lower on the fp64 matrix core (NX in 13..17, NU <= 4): the three products accumulate in one 16x16 tile (9 MFMAs), the 17th k is a
-// rank-1 term on the results, and row 16 of the result (the only border entries in the lower triangle) is three partial dot products per
-// entry on 51 lanes, summed through the crossbar.  Writes the lower triangle of the core and the whole last row.
+// build_Y_lower on the fp64 matrix core (NX in 13..17, NU <= 4) with M1 = A diag(pix) formed on the fly: the three products accumulate in
+// one 16x16 tile (9 MFMAs), the 17th k is a rank-1 term on the results, and row 16 of the result (the only border entries in the lower
+// triangle) is three partial dot products per entry on 51 lanes, summed through the crossbar.  useM = false drops the M1 terms (stage 0).
+// Writes the lower triangle of the core and the whole last row; every load precedes the first store, so Y may be Tm's buffer.
 template <int NX, int NU>
-__device__ __forceinline__ void build_Y_mfma(const double *M1, const double *A, const double *B, const double *piu, const double *Tm, bool useT,
+__device__ __forceinline__ void build_Y_mfma(const double *A, const double *pix, const double *B, const double *piu, const double *Tm, bool useM,
                                              const double *d, double delta, double *Y, int lane) {
     static_assert(NX >= 5 && NX <= 17 && NU <= 4, "one 16x16 tile");
     constexpr int MC = NX < 16 ? NX : 16;
@@ -272,15 +274,14 @@ __device__ __forceinline__ void build_Y_mfma(const double *M1, const double *A, 
     mfma_d4 acc;
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int i = lk + 4 * r; acc[r] = (i == li && i < MC) ? d[min(i, NX - 1)] + delta : 0.0; }
+    if (useM) {
 #pragma unroll
-    for (int k0 = 0; k0 < MC; k0 += 4) {
-        const int k = k0 + lk, kc = min(k, MC - 1);
-        const bool ok = (li < MC) && (k < MC);
-        const double m1 = M1[lc * NX + kc], av = A[lc * NX + kc];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? m1 : 0.0, ok ? av : 0.0, acc, 0, 0, 0);              // M1 A'
-        if (useT) {
-            const double tv = Tm[lc * NX + kc];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? -tv : 0.0, ok ? m1 : 0.0, acc, 0, 0, 0);         // - T M1'
+        for (int k0 = 0; k0 < MC; k0 += 4) {
+            const int k = k0 + lk, kc = min(k, MC - 1);
+            const bool ok = (li < MC) && (k < MC);
+            const double av = A[lc * NX + kc], m1 = av * pix[kc], tv = Tm[lc * NX + kc];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? m1 : 0.0, ok ? av : 0.0, acc, 0, 0, 0);              // M1 A'
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? -tv : 0.0, ok ? m1 : 0.0, acc, 0, 0, 0);            // - T M1'
         }
     }
     {
@@ -290,25 +291,29 @@ __device__ __forceinline__ void build_Y_mfma(const double *M1, const double *A, 
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? bv * piu[u] : 0.0, ok ? bv : 0.0, acc, 0, 0, 0);     // B diag(piu) B'
     }
     if constexpr (NX == 17) {
-        const double a16 = A[lc * NX + 16], m16 = M1[lc * NX + 16];
+        if (useM) {
+            const double a16 = A[lc * NX + 16], p16 = pix[16], m16 = a16 * p16;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int i = lk + 4 * r;
-            acc[r] = fma(M1[i * NX + 16], a16, acc[r]);
-            if (useT) acc[r] = fma(-Tm[i * NX + 16], m16, acc[r]);
+            for (int r = 0; r < 4; r++) {
+                const int i = lk + 4 * r;
+                acc[r] = fma(A[i * NX + 16] * p16, a16, acc[r]);
+                acc[r] = fma(-Tm[i * NX + 16], m16, acc[r]);
+            }
         }
     }
-    double srow = 0.0;      // row 16 of the result, computed before anything is stored: Y may be Tm's (or M1's) buffer
+    double srow = 0.0;      // row 16 of the result, computed before anything is stored
     if constexpr (NX == 17) {
         const int g = lane / 17, j = lane % 17;
         double v = 0.0;
         if (g == 0) {
+            if (useM) {
 #pragma unroll
-            for (int k = 0; k < NX; k++) v = fma(M1[16 * NX + k], A[j * NX + k], v);
+                for (int k = 0; k < NX; k++) v = fma(A[16 * NX + k] * pix[k], A[j * NX + k], v);
+            }
         } else if (g == 1) {
-            if (useT) {
+            if (useM) {
 #pragma unroll
-                for (int k = 0; k < NX; k++) v = fma(-Tm[16 * NX + k], M1[j * NX + k], v);
+                for (int k = 0; k < NX; k++) v = fma(-Tm[16 * NX + k], A[j * NX + k] * pix[k], v);
             }
         } else if (g == 2) {
 #pragma unroll
@@ -316,7 +321,6 @@ __device__ __forceinline__ void build_Y_mfma(const double *M1, const double *A, 
             if (j == 16) v += d[16] + delta;
         }
         srow = v + __shfl(v, lane + 17) + __shfl(v, lane + 34);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int i = lk + 4 * r; if (i < MC && li <= i) Y[i * NX + li] = acc[r]; }

@@ -195,7 +195,7 @@ def main():
             out["roofline"]["single_slice"] = {"achieved": a1, "frac": a1 / 8000.0, "avg_launch_ms": ms1 / max(1, n1), "launches": n1,
                                                "algorithmic_bytes_per_launch": per_inst * float(sw1) / max(1, n1),
                                                "traffic": json.load(open(pmc1)).get("k_ne_fwd_bytes_per_launch") if os.path.exists(pmc1) else None,
-                                               "note": "whole batch as one slice, 2 steps after the timed region (profiles/r01: v4_kernel_stats.csv, pmc_traffic_single_slice.json)"}
+                                               "note": "whole batch as one slice, 2 steps after the timed region (traffic: profiles/r01/pmc_traffic_single_slice.json)"}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(batch, min(B, 4096), budget_s=12.0)
         else:

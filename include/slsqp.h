@@ -68,7 +68,7 @@ typedef struct {
     int max_scp_iter;    /* MAX_ITER_SCP (100, SCP_SLS_jit.py:47): cap of the SCP loop of slsqp_cl_step in converge mode (rti <= 0) */
     double scp_eps;      /* epsilon_convergence (1e-10, SCP_SLS_jit.py:29): SCP converged when |delta_vec|inf < scp_eps */
     int precision;       /* 0 (default): fp64 throughout.  1: mixed -- block factorisations, stored inverses and substitutions in fp32,
-                            right-hand sides / residuals / KKT certificate in fp64, one more refinement solve per polish; instances
+                            right-hand sides / residuals / KKT certificate in fp64, two more refinement solves per polish; instances
                             that do not certify are solved again in fp64 (BASELINE config 3, "fp32 vs fp64") */
 } slsqp_opts;
 

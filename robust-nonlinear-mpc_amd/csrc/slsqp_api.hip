@@ -363,7 +363,8 @@ static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int w
     a.state = h->qpstate; a.n_active = h->counter + 1; a.warm = warm; a.warm_rounds = o->warm_rounds;
     a.init_s = getenv("SLSQP_INIT_S") ? atof(getenv("SLSQP_INIT_S")) : 1.0; a.init_lam = getenv("SLSQP_INIT_LAM") ? atof(getenv("SLSQP_INIT_LAM")) : 0.0;
     const bool mx = o->precision == 1;
-    a.n_refine = mx ? 3 : 2;
+    a.n_refine = mx ? 3 : 1;   // fp64: one refinement solve; its forward sweep measures the dynamics residual of the first solve (certificate)
+    if (getenv("SLSQP_NREFINE")) a.n_refine = atoi(getenv("SLSQP_NREFINE"));
     a.early_ctol = mx ? 1e-2 : 1e-6;
     auto go = [&](const QpArgs &q, bool m) {
         if (h->d.nx == 4) return launch_qp_t<4, 1>(h, q, o->qp_max_iter, m);
@@ -381,7 +382,7 @@ static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int w
         h->mx_retry = nretry; h->mx_retry_total += nretry;
         if (nretry > 0) {
             QpArgs r = a;
-            r.run = h->retry; r.warm = 0; r.n_refine = 2; r.early_ctol = 1e-6;
+            r.run = h->retry; r.warm = 0; r.n_refine = 1; r.early_ctol = 1e-6;
             if (go(r, false)) return -1;
         }
     }

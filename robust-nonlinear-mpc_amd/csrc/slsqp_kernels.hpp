@@ -79,7 +79,7 @@ struct QpArgs {
     const double *prox;       // per-instance proximal weight added to the diagonal cost (element b * prox_stride), or NULL
     int prox_stride;
     unsigned long long *inst_launches;   // += 1 per instance forward sweep (roofline accounting of bench.py)
-    int n_refine;             // refinement solves per polish (2 in fp64, 3 with fp32 factorisations)
+    int n_refine;             // refinement solves per polish (1 in fp64, 3 with fp32 factorisations)
     double early_ctol;        // tolerance (relative to max(1,|q|inf)) of the look at the un-refined polish solve: its accuracy class
 };
 
@@ -463,7 +463,7 @@ __device__ __forceinline__ Elem elem_of(int e, int n, int N, const double *ub, c
 //   2. Mehrotra predictor-corrector interior point; every Newton system is reduced to the block-tridiagonal
 //      normal equations  (E Pi E') dnu = rhs,  Pi = (P + Sigma)^-1 diagonal, factorised stage by stage,
 //   3. active-set polish (the OSQP-polish idea, qp_jit.py:546 `polishing=True`): fix the variables the interior
-//      point identifies as active, re-solve the KKT system exactly with 2 refinement steps, accept only if the
+//      point identifies as active, re-solve the KKT system exactly with a refinement step, accept only if the
 //      KKT certificate (stationarity, box feasibility, multiplier signs) holds to 1e-9; otherwise correct the
 //      active set (primal-dual active-set step) and repeat, at most 6 times.
 // One tick = one block-tridiagonal solve (forward sweep, backward sweep) + the elementwise work that consumes it and
@@ -737,7 +737,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 V[e] = zn - pi * r1;
             }
             // n_refine refinement solves per polish: P_POL1 repeats until the last one, which runs as P_POL2 (s.pad counts them)
-            if (phase == P_POL0) { s.pad = 0.0; phase = P_POL1; }
+            if (phase == P_POL0) { s.pad = 0.0; phase = (a.n_refine <= 1) ? P_POL2 : P_POL1; }
             else { s.pad += 1.0; phase = (s.pad + 1.0 >= (double)a.n_refine) ? P_POL2 : P_POL1; }
         } else {
             double vst = 0.0, vbox = 0.0, vsign = 0.0;

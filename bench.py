@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--model", default="rocket")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--slices", type=int, default=3, help="independent slices of the rank's batch, each with its own handle / HIP stream / host thread")
+    ap.add_argument("--qp-eps", type=float, default=None, help="interior-point tolerance before the polish (default: the library's 1e-6)")
     ap.add_argument("--precision", type=int, default=0, help="0: fp64 (headline); 1: mixed fp32 factorisation / fp64 residuals (secondary figure)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
@@ -106,6 +107,8 @@ def main():
         f.set_rti_steps(m.fast_sls_rti_steps if args.model == "rocket" else 1)
         f.opts.warm_rounds = int(os.environ.get('QP_WARM_ROUNDS', '4'))
         f.opts.precision = args.precision
+        if args.qp_eps is not None:
+            f.opts.qp_eps = args.qp_eps
         f.opts.warm_start = 0   # QP#1 of every step is solved cold (fresh Monte-Carlo instances); QP#2 warm-starts from QP#1
         return f
 

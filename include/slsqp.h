@@ -130,6 +130,11 @@ int slsqp_linearize(slsqp_handle *h, const double *X, const double *U, int loc);
    scp_delta_max (1) + all names of the fast-SLS result (for each instance: of its last fast-SLS solve). */
 int slsqp_cl_init(slsqp_handle *h, const double *x_meas, const double *X_nom, const double *U_nom, const double *u_init, int loc);
 int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc, const slsqp_opts *opts);
+/* Device-side log of the closed loop: every following slsqp_cl_step stores what the scripts keep per MPC step
+   (expe/main_rocket_robust_closed_loop.py:160-178) in entry `step` of (B, max_steps, ...) device buffers, so a Monte-Carlo run makes no
+   host round trip per step.  slsqp_get names (per instance): log_state (S,nx) log_u0 (S,nu) log_nominal_x (S,N+1,nx) log_nominal_u (S,N,nu)
+   log_backoff_x (S,N+1,nx) log_backoff_u (S,N,nu) log_success[int32] (S) log_scp_iterations[int32] (S).  slsqp_cl_init restarts at entry 0. */
+int slsqp_cl_log(slsqp_handle *h, int max_steps);
 
 /* ---- nominal-trajectory initialiser: replaces the reference's IPOPT call for the first MPC step
    (SCP_SLS.solve_nominal_trajectory solver/SCP_SLS_jit.py:161-188, NLP of solver/nlp.py:158-217:

@@ -74,6 +74,29 @@ class ClosedLoopMPC:
             t_qp_ms=f.timing_ms()["qp"], t_riccati_ms=f.timing_ms()["sweep"],
         )
 
+    def run_on_device(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False):
+        """Same result as run(), but the per-step records stay in device buffers (slsqp_cl_log) and are read back once at the end: the only
+        host -> device traffic per MPC step is the disturbance sample (B,nx)."""
+        f, m, N, B = self.f, self.m, self.N, self.B
+        L.check(f.lib.slsqp_cl_log(f.h, int(steps)))
+        self.reset(x0, X_nom, U_nom, solve_nominal=solve_nominal)
+        t_qp, t_ric = np.zeros((steps, 1)), np.zeros((steps, 1))
+        for i in range(steps):
+            self.step(None if W is None else W[i], fetch=False)
+            t = f.timing_ms()
+            t_qp[i], t_ric[i] = t["qp"], t["sweep"]
+        lx = f.get("log_nominal_x", (steps, N + 1, m.nx)); lu = f.get("log_nominal_u", (steps, N, m.nu))
+        lbx = f.get("log_backoff_x", (steps, N + 1, m.nx)); lbu = f.get("log_backoff_u", (steps, N, m.nu))
+        u0 = f.get("log_u0", (steps, m.nu))
+        return dict(
+            state_trajectory=f.get("log_state", (steps, m.nx)).transpose(0, 2, 1).copy(),
+            input_trajectory=u0[:, :max(steps - 1, 0)].transpose(0, 2, 1).copy(),
+            nominal_trajectory_x=lx.transpose(0, 3, 2, 1).copy(), nominal_trajectory_u=lu.transpose(0, 3, 2, 1).copy(),
+            backoff_trajectory_x=lbx.transpose(0, 3, 2, 1).copy(), backoff_trajectory_u=lbu.transpose(0, 3, 2, 1).copy(),
+            t_jac=np.full((steps, 1), np.nan), t_qp=t_qp, t_riccati=t_ric,
+            success=f.get("log_success", (steps,), np.int32).astype(bool), scp_iterations=f.get("log_scp_iterations", (steps,), np.int32),
+        )
+
     def run(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False):
         """Closed loop of `steps` MPC steps from x0 (B,nx); W (steps,B,nx) disturbance samples or None.  Returns arrays laid out
         like the reference's npz (expe/main_rocket_robust_closed_loop.py:189-206) with a leading batch axis."""

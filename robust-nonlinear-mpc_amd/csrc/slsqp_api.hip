@@ -61,6 +61,8 @@ struct slsqp_handle {
     double t_total, t_qp, t_sweep, t_fwd; int n_fwd; double fwd_inst;   // fwd_inst: sum over launches of instances that did work
     std::map<std::string, std::pair<void *, size_t>> named;  // name -> (device ptr, bytes per instance)
     unsigned long long *inst_launches;                       // device counter: instance-sweeps done by k_ne_fwd (roofline accounting)
+    int log_steps;                                           // device-side closed-loop log (slsqp_cl_log): capacity in MPC steps, 0 = off
+    double *lg_x, *lg_u, *lg_bx, *lg_bu, *lg_state, *lg_u0; int *lg_succ, *lg_it;
 };
 
 static Costs costs_of(slsqp_handle *h) {
@@ -121,6 +123,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->nom_st, B * 12); rc |= dalloc(&h->nom_need_lin, B); rc |= dalloc(&h->nom_status, B); rc |= dalloc(&h->nom_iters, B);
     rc |= dalloc(&h->mapA, (size_t)N * nx * nx); rc |= dalloc(&h->mapB, (size_t)N * nx * nu);
     rc |= dalloc(&h->inst_launches, (size_t)1);
+    h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
     h->kev.resize(2 * 256); for (auto &e : h->kev) hipEventCreate(&e);
@@ -171,6 +174,7 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     hipSetDevice(h->dev);
     hipStreamSynchronize(h->st);
     hipFree(h->inst_launches);
+    { void *lg[] = {h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_succ, h->lg_it}; for (void *p : lg) if (p) hipFree(p); }
     void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->g_raw, h->Xn, h->Un, h->xmeas, h->x0arg, h->u0, h->wbuf, h->u_init, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
                     h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->ws, h->qpstate, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
                     h->backoff_u, h->K, h->status, h->iters, h->itnum, h->has_prev, h->conv, h->alive, h->mask, h->success, h->infeas,
@@ -659,6 +663,29 @@ extern "C" int slsqp_nominal_solve(slsqp_handle *h, int max_qp, double tol, doub
     return 0;
 }
 
+// Device-side log of the closed loop: after this call every slsqp_cl_step stores what the reference's scripts keep per MPC step
+// (expe/main_rocket_robust_closed_loop.py:160-178) into entry cl_steps of (B, max_steps, ...) buffers; slsqp_get names: log_state (S,nx)
+// log_u0 (S,nu) log_nominal_x (S,N+1,nx) log_nominal_u (S,N,nu) log_backoff_x (S,N+1,nx) log_backoff_u (S,N,nu) log_success[int32] (S)
+// log_scp_iterations[int32] (S).  slsqp_cl_init restarts at entry 0.
+extern "C" int slsqp_cl_log(slsqp_handle *h, int max_steps) {
+    hipSetDevice(h->dev);
+    if (max_steps < 1) return fail("slsqp_cl_log: max_steps must be >= 1");
+    { void *lg[] = {h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_succ, h->lg_it}; for (void *p : lg) if (p) hipFree(p); }
+    const slsqp_dims &d = h->d;
+    const size_t B = h->B, S = max_steps, nX = (size_t)(d.N + 1) * d.nx, nU = (size_t)d.N * d.nu;
+    int rc = 0;
+    rc |= dalloc(&h->lg_x, B * S * nX); rc |= dalloc(&h->lg_u, B * S * nU); rc |= dalloc(&h->lg_bx, B * S * nX); rc |= dalloc(&h->lg_bu, B * S * nU);
+    rc |= dalloc(&h->lg_state, B * S * d.nx); rc |= dalloc(&h->lg_u0, B * S * d.nu); rc |= dalloc(&h->lg_succ, B * S); rc |= dalloc(&h->lg_it, B * S);
+    if (rc) { h->log_steps = 0; return -1; }
+    h->log_steps = max_steps;
+    auto reg = [&](const char *nm, void *p, size_t bytes) { h->named[nm] = {p, bytes}; };
+    reg("log_nominal_x", h->lg_x, sizeof(double) * S * nX); reg("log_nominal_u", h->lg_u, sizeof(double) * S * nU);
+    reg("log_backoff_x", h->lg_bx, sizeof(double) * S * nX); reg("log_backoff_u", h->lg_bu, sizeof(double) * S * nU);
+    reg("log_state", h->lg_state, sizeof(double) * S * d.nx); reg("log_u0", h->lg_u0, sizeof(double) * S * d.nu);
+    reg("log_success", h->lg_succ, sizeof(int) * S); reg("log_scp_iterations", h->lg_it, sizeof(int) * S);
+    return 0;
+}
+
 // One MPC step for the whole batch: [warm-start shift + solver reset] -> rti x (linearise, fast-SLS solve of x_nom0 - x_meas,
 // nominal += delta) -> u0 = first nominal input -> plant step x_meas <- ddyn(x_meas,u0) + E w.   w (B,nx) or NULL (no noise).
 extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc, const slsqp_opts *opts) {
@@ -700,6 +727,11 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
         HIPCHK(hipStreamSynchronize(h->st));
         if (nact == 0 || ii + 1 == max_it) break;
         if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, h->scp_active)) return -1;   // update_jacobian for the next iteration (:138)
+    }
+    if (h->log_steps > 0 && h->cl_steps < h->log_steps) {
+        ClLogArgs la{h->B, d.N, d.nx, d.nu, h->log_steps, h->cl_steps, h->Xn, h->Un, h->backoff_x, h->backoff_u, h->scp_success, h->scp_iters,
+                     h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_succ, h->lg_it};
+        hipLaunchKernelGGL(k_cl_log, dim3(1024), dim3(256), 0, h->st, la);
     }
     if (h->model_id == 0) hipLaunchKernelGGL((k_cl_shift_plant<0>), dim3(gb), dim3(64), 0, h->st, a, 0, 1);
     else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_shift_plant<1>), dim3(gb), dim3(64), 0, h->st, a, 0, 1);

@@ -1398,6 +1398,35 @@ __global__ void k_cl_x0arg(ClArgs a) {
         a.x0arg[t] = a.Xn[(size_t)b * (a.N + 1) * a.NX + i] - a.xmeas[t];
     }
 }
+// device-side log of a closed-loop run (what the scripts store per MPC step, expe/main_rocket_robust_closed_loop.py:160-178): entry `step`
+// of (B, S, ...) buffers, so a whole Monte-Carlo run needs no host round trip per step
+struct ClLogArgs {
+    int B, N, NX, NU, S, step;
+    const double *Xn, *Un, *bx, *bu;
+    const int *success, *scp_iters;
+    double *lx, *lu, *lbx, *lbu, *lstate, *lu0;
+    int *lsucc, *lit;
+};
+__global__ void k_cl_log(ClLogArgs a) {
+    const int nX = (a.N + 1) * a.NX, nU = a.N * a.NU, per = 2 * nX + 2 * nU;
+    const size_t tot = (size_t)a.B * per;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+        const int b = t / per;
+        int o = t % per;
+        const size_t e = (size_t)b * a.S + a.step;
+        if (o < nX) {
+            const double v = a.Xn[(size_t)b * nX + o];
+            a.lx[e * nX + o] = v;
+            if (o < a.NX) a.lstate[e * a.NX + o] = v;
+        } else if ((o -= nX) < nU) {
+            const double v = a.Un[(size_t)b * nU + o];
+            a.lu[e * nU + o] = v;
+            if (o < a.NU) a.lu0[e * a.NU + o] = v;
+        } else if ((o -= nU) < nX) a.lbx[e * nX + o] = a.bx[(size_t)b * nX + o];
+        else { o -= nX; a.lbu[e * nU + o] = a.bu[(size_t)b * nU + o]; }
+        if (t % per == 0) { a.lsucc[e] = a.success[b]; a.lit[e] = a.scp_iters[b]; }
+    }
+}
 // warm-start shift (SCP_SLS_jit.py:508-518): x_k <- x_{k+1}, u_k <- u_{k+1}, u_{N-1} kept, x_N <- ddyn(x_N, u_{N-1});
 // plant step (expe/main_rocket...:180-182): x_meas <- ddyn(x_meas, u0) + E w.   One thread per instance.
 template <int MODEL>

@@ -19,7 +19,7 @@ def _run_slice(model, N, seeds, steps, x0, device, noise, solve_nominal):
     B = len(seeds)
     W = np.stack([disturbance_stream(s, steps, model.nx) for s in seeds], axis=1) if noise else None   # (steps, B, nx)
     cl = ClosedLoopMPC(model, N, B, device=device)
-    out = cl.run(np.tile(np.asarray(x0, dtype=float), (B, 1)), steps, W, solve_nominal=solve_nominal)
+    out = cl.run_on_device(np.tile(np.asarray(x0, dtype=float), (B, 1)), steps, W, solve_nominal=solve_nominal)
     if cl.nlp_status is not None:
         out.update(nlp_status=cl.nlp_status, nlp_iterations=cl.nlp_iterations)
     cl.close()

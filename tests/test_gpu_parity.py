@@ -215,6 +215,12 @@ def test_closed_loop_vs_oracle(model, N, steps, amp):
     cl = ClosedLoopMPC(m, N, B)
     out = cl.run(x0, steps, W)
     cl.close()
+    cl = ClosedLoopMPC(m, N, B)                 # a fresh handle: the QP warm start remembers the previous run's active sets
+    dev = cl.run_on_device(x0, steps, W)       # records kept in device buffers, one read-back at the end: same bits
+    cl.close()
+    for k in ("state_trajectory", "input_trajectory", "nominal_trajectory_x", "nominal_trajectory_u", "backoff_trajectory_x",
+              "backoff_trajectory_u", "success", "scp_iterations"):
+        assert np.array_equal(out[k], dev[k]), k
     for b in range(B):
         ref = run_oracle_closed_loop(m, N, x0[b], steps, m.rti, m.fast_sls_rti_steps, None if W is None else W[:, b])
         assert list(out["success"][b]) == list(ref["success"])

@@ -328,9 +328,10 @@ static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter, bool mx) 
     // every instance needs 1 (start) + 2 per interior-point iteration + (1 + n_refine) per polish round ticks; poll the number of
     // unfinished instances every few ticks instead of running the worst case
     const int max_ticks = 1 + 2 * max_iter + 3 + 2 * 10 + 8 + 2 + 16;
+    static const int first_burst = getenv("SLSQP_BURST0") ? atoi(getenv("SLSQP_BURST0")) : 12, tail_burst = getenv("SLSQP_BURST") ? atoi(getenv("SLSQP_BURST")) : 3;
     int tick = 0, active = 1;
     while (tick < max_ticks && active > 0) {
-        const int burst = tick < 12 ? 12 : 3;
+        const int burst = tick < first_burst ? first_burst : tail_burst;
         for (int i = 0; i < burst; i++, tick++) {
             const bool timed = h->n_kev + 2 <= (int)h->kev.size();
             if (timed) hipEventRecord(h->kev[h->n_kev], h->st);

@@ -20,7 +20,7 @@
  *     termination test, polish with regularised KKT + iterative refinement) from memory of that paper and
  *     the public documentation.  PARITY UNPINNED: there is no OSQP output anywhere in the reference to
  *     check against; the restatement is validated by KKT optimality certificates instead
- *     (tests/test_oracle_qp.py).  One deliberate implementation difference, mathematically neutral: the
+ *     (tests/test_host_cpu.py: KKT certificates, unconstrained case against the reference's own Riccati recursion).  One deliberate implementation difference, mathematically neutral: the
  *     quasi-definite KKT system of each ADMM step is solved in its reduced form
  *     (P + sigma I + A' diag(rho) A) x = rhs with a banded Cholesky (stage ordering, half bandwidth
  *     nx+2nu+nx-1) instead of QDLDL + AMD.

@@ -77,6 +77,38 @@ def test_oracle_qp_kkt_certificate(model):
     assert np.allclose(x[: m.nx], -inst.x0_arg, atol=1e-9)
 
 
+@pytest.mark.parametrize("model,amp", [("pendulum", 1.0), ("quadrotor", 1.0), ("rocket", 0.5)])
+def test_oracle_qp_agrees_with_an_independent_interior_point(model, amp):
+    """QP parity is "unpinned" (no OSQP output in the reference), so the oracle's OSQP-class ADMM restatement is cross-checked on the CPU
+    against a second algorithm that shares nothing with it: a dense Mehrotra interior point in numpy (tests/ref_ipm.py)."""
+    from oracle import oracle as O
+    from problems import make_instance, oracle_dims, qp1_bounds
+    from ref_ipm import build_equalities, qp_box
+    for seed in range(2):
+        inst = make_instance(model, seed, amp)
+        m, N = inst.m, inst.N
+        nx, nz = m.nx, m.nz
+        n = nz * N + nx
+        l, u = qp1_bounds(inst)
+        xo, yo, info = O.qp_solve(oracle_dims(inst), inst.A, inst.B, m.G, m.Gf, m.Q, m.R, m.Qf, inst.q, l, u, O.tight_settings())
+        assert info.status in (1, 2)
+        SR = nx + m.ni
+        hi, lo = np.full(n, 1e20), np.full(n, -1e20)
+        for k in range(N):
+            hi[k * nz:(k + 1) * nz] = u[k * SR + nx:k * SR + nx + nz]
+            lo[k * nz:(k + 1) * nz] = -u[k * SR + nx + nz:k * SR + nx + 2 * nz]
+        hi[N * nz:], lo[N * nz:] = u[N * SR:N * SR + nx], -u[N * SR + nx:N * SR + 2 * nx]
+        hi[:nx], lo[:nx] = 1e20, -1e20                                    # x_0 is pinned by its equality rows
+        c = np.stack([-0.5 * (u[k * SR:k * SR + nx] + l[k * SR:k * SR + nx]) for k in range(N)])
+        E, e = build_equalities(inst.A, inst.B, c, 0.5 * (l[-nx:] + u[-nx:]))
+        Pd = 2.0 * np.concatenate([np.concatenate([np.diag(m.Q), np.diag(m.R)])] * N + [np.diag(m.Qf)])
+        z, nu, lu, ll, ok, its = qp_box(Pd, inst.q, E, e, lo, hi)
+        assert ok, its
+        # like OSQP, the restatement only promises eps-accuracy when its polish step fails; with a successful polish it is exact
+        tol = 1e-6 if (info.status == 1 and info.polish_status == 1) else 1e-4
+        assert np.max(np.abs(z - xo)) < tol * max(1.0, np.max(np.abs(xo)))
+
+
 def test_oracle_qp_unconstrained_equals_lq_riccati():
     """With slack bounds the QP optimum is the LQ solution obtained with OCP.riccati_step (solver/ocp.py:103-109)."""
     from oracle import oracle as O

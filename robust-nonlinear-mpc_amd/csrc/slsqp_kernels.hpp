@@ -1017,8 +1017,9 @@ struct SweepArgs {
 
 template <int NX, int NU>
 __host__ __device__ constexpr int sweep_lds_doubles() {
-    // sA sS sYm sAcl (4 NX^2; the propagate phase reuses sS / sYm for Phi, NW == NX) + sB sX sF sK sPu (5 NX NU) + sH (NU^2) + sC (NX+NU)
-    return 4 * NX * NX + 5 * NX * NU + NU * NU + (NX + NU) + 8;
+    // sA sS sYm (3 NX^2: A + B K is formed in place in sA, y (A + B K) in sS, the propagate phase reuses sS / sYm for Phi, NW == NX)
+    // + sB sX sF sK sPu (5 NX NU) + sH (NU^2) + sC (NX+NU)
+    return 3 * NX * NX + 5 * NX * NU + NU * NU + (NX + NU) + 8;
 }
 
 // SWEEP_MFMA (default 1): the dense products of the sweep (A'S, y Acl, Acl Phi, B'S, x A, K Phi, A + B K) run on the fp64 matrix core for
@@ -1053,8 +1054,9 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
     if (a.run && !a.run[b]) return;
     extern __shared__ double sm[];
     double *p = sm;
-    double *sA = p; p += NX * NX; double *sS = p; p += NX * NX; double *sYm = p; p += NX * NX; double *sAcl = p; p += NX * NX;
-    double *sSn = sA;                      // y (A + B K) lands where A_k was: A_k is dead once Acl is formed
+    double *sA = p; p += NX * NX; double *sS = p; p += NX * NX; double *sYm = p; p += NX * NX;
+    double *sAcl = sA;                     // A + B K replaces A_k in place (every use of A_k precedes it)
+    double *sSn = sS;                      // y (A + B K) lands where S_{k+1} was (dead once B'S and A'S are formed), symmetrised in place
     double *sPhi = sS, *sPhi2 = sYm;       // the Riccati buffers are dead in the propagate phase
     double *sB = p; p += NX * NU; double *sX = p; p += NX * NU; double *sF = p; p += NX * NU; double *sK = p; p += NX * NU;
     double *sPu = p; p += NU * NW; double *sH = p; p += NU * NU; double *sC = p; p += NZ;
@@ -1157,9 +1159,12 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
         wla::gemm_blk<NX, NX, NX, false, false, 3, 2, false>(sYm, NX, sAcl, NX, sSn, NX, 1.0, lane);  // y (A + B K)
         wla::wsync();
 #pragma unroll
-        for (int o = lane; o < NX * NX; o += 64) {
+        for (int o = lane; o < NX * NX; o += 64) {   // S = (Sn + Sn')/2 + diag, in place: the lane of (i,j), i >= j, writes both (i,j) and (j,i)
             const int i = o / NX, jj = o % NX;
-            sS[o] = 0.5 * (sSn[o] + sSn[jj * NX + i]) + ((i == jj) ? sC[i] : 0.0);
+            if (i >= jj) {
+                const double v = 0.5 * (sSn[o] + sSn[jj * NX + i]) + ((i == jj) ? sC[i] : 0.0);
+                sS[o] = v; sS[jj * NX + i] = v;
+            }
         }
         wla::wsync();
     }

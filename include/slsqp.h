@@ -99,7 +99,7 @@ int slsqp_update_linear_cost(slsqp_handle *h, const double *q, int loc); /* q (B
 int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts);
 
 /* Fetch a result array by name into `out` (host or device).  Names and shapes (B leading):
-   primal_vec (n) dual_vec (m-nx) cost_nominal (1) status[int32] (1) qp_iters[int32] (1) iteration_number[int32] (1)
+   primal_vec (n) dual_vec (m-nx) cost_nominal (1) cost_tube (1; SLS.eval_cost of the last sweep, util/SLS.py:38-46) status[int32] (1) qp_iters[int32] (1) iteration_number[int32] (1)
    beta (N,N,ni) beta_f (N+1,ni_f) backoff (N,ni) backoff_f (ni_f) backoff_x (N+1,nx) backoff_u (N,nu)
    eta (N,N,ni) eta_f (N+1,ni_f) K (N,N+1,nu,nx) ubg (m-nx) lbg (m-nx) kkt (8) pin_dual (nx) success[int32] (1)
    and the current problem data: A (N,nx,nx) Bm (N,nx,nu) c (N,nx) g (N,ni) gN (ni_f) q (n) */

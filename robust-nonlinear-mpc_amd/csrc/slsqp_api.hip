@@ -61,6 +61,7 @@ struct slsqp_handle {
     double t_total, t_qp, t_sweep, t_fwd; int n_fwd; double fwd_inst;   // fwd_inst: sum over launches of instances that did work
     std::map<std::string, std::pair<void *, size_t>> named;  // name -> (device ptr, bytes per instance)
     unsigned long long *inst_launches;                       // device counter: instance-sweeps done by k_ne_fwd (roofline accounting)
+    double *ct_part, *cost_tube;                             // sweep's per-column parts of cost_tube^2 and the result
     int log_steps;                                           // device-side closed-loop log (slsqp_cl_log): capacity in MPC steps, 0 = off
     double *lg_x, *lg_u, *lg_bx, *lg_bu, *lg_state, *lg_u0; int *lg_succ, *lg_it;
 };
@@ -122,7 +123,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->retry, B); h->mx_retry = 0; h->mx_retry_total = 0;
     rc |= dalloc(&h->nom_st, B * 12); rc |= dalloc(&h->nom_need_lin, B); rc |= dalloc(&h->nom_status, B); rc |= dalloc(&h->nom_iters, B);
     rc |= dalloc(&h->mapA, (size_t)N * nx * nx); rc |= dalloc(&h->mapB, (size_t)N * nx * nu);
-    rc |= dalloc(&h->inst_launches, (size_t)1);
+    rc |= dalloc(&h->inst_launches, (size_t)1); rc |= dalloc(&h->ct_part, B * (N + 1)); rc |= dalloc(&h->cost_tube, B);
     h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
@@ -162,7 +163,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     reg("backoff_x", h->backoff_x, sizeof(double) * (N + 1) * nx); reg("backoff_u", h->backoff_u, sizeof(double) * N * nu);
     reg("eta", h->eta, sizeof(double) * N * N * ni); reg("eta_f", h->eta_f, sizeof(double) * (N + 1) * nif);
     reg("K", h->K, sizeof(double) * N * (N + 1) * nu * nx); reg("ubg", h->ubg, sizeof(double) * h->mb); reg("lbg", h->lbg, sizeof(double) * h->mb);
-    reg("kkt", h->kkt, sizeof(double) * 8);
+    reg("kkt", h->kkt, sizeof(double) * 8); reg("cost_tube", h->cost_tube, sizeof(double));
     reg("nominal_x", h->Xn, sizeof(double) * (N + 1) * nx); reg("nominal_u", h->Un, sizeof(double) * N * nu); reg("x_meas", h->xmeas, sizeof(double) * nx); reg("u0", h->u0, sizeof(double) * nu);
     reg("A", h->A, sizeof(double) * N * nx * nx); reg("Bm", h->Bm, sizeof(double) * N * nx * nu); reg("c", h->c, sizeof(double) * N * nx);
     reg("g", h->g, sizeof(double) * N * ni); reg("gN", h->gN, sizeof(double) * nif); reg("q", h->q, sizeof(double) * h->n); reg("pin_dual", h->pin_dual, sizeof(double) * nx);
@@ -173,7 +174,7 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     if (!h) return;
     hipSetDevice(h->dev);
     hipStreamSynchronize(h->st);
-    hipFree(h->inst_launches);
+    hipFree(h->inst_launches); hipFree(h->ct_part); hipFree(h->cost_tube);
     { void *lg[] = {h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_succ, h->lg_it}; for (void *p : lg) if (p) hipFree(p); }
     void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->g_raw, h->Xn, h->Un, h->xmeas, h->x0arg, h->u0, h->wbuf, h->u_init, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
                     h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->ws, h->qpstate, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
@@ -404,7 +405,7 @@ static int launch_sweep_t(slsqp_handle *h, const SweepArgs &a) {
 static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, const double *eta_f, double eps) {
     SweepArgs a;
     a.B = h->B; a.N = h->d.N; a.NW = h->d.nw; a.A = h->A; a.Bm = h->Bm; a.E = h->E; a.E_per_instance = 0; a.eta = eta; a.eta_f = eta_f;
-    a.run = run; a.cst = costs_of(h); a.K = h->K; a.beta = h->beta; a.beta_f = h->beta_f; a.eps = eps;
+    a.run = run; a.cst = costs_of(h); a.K = h->K; a.beta = h->beta; a.beta_f = h->beta_f; a.ct_part = h->ct_part; a.eps = eps;
     if (h->d.nx == 4) return launch_sweep_t<4, 1>(h, a);
     if (h->d.nx == 13) return launch_sweep_t<13, 4>(h, a);
     return launch_sweep_t<17, 4>(h, a);
@@ -457,7 +458,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         HIPCHK(hipEventRecord(h->ev[3], h->st));
         if (launch_sweep(h, h->mask, h->eta, h->eta_f, o.eps_backoff)) return -1;
         HIPCHK(hipEventRecord(h->ev[4], h->st));
-        TightenArgs ta{B, d.N, d.nx, d.nu, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1};
+        TightenArgs ta{B, d.N, d.nx, d.nu, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1, h->ct_part, h->cost_tube};
         hipLaunchKernelGGL(k_tighten, dim3(B), dim3(128), 0, h->st, ta);
         int nmask = 0;
         HIPCHK(hipMemcpyAsync(&nmask, h->counter, sizeof(int), hipMemcpyDeviceToHost, h->st));
@@ -834,7 +835,7 @@ extern "C" int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta
     HIPCHK(hipEventRecord(h->ev[0], h->st));
     if (launch_sweep(h, nullptr, h->eta, h->eta_f, 1e-10)) return -1;
     HIPCHK(hipEventRecord(h->ev[1], h->st));
-    TightenArgs ta{h->B, d.N, d.nx, d.nu, h->beta, h->beta_f, h->g, h->gf_raw, h->c, nullptr, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 0};
+    TightenArgs ta{h->B, d.N, d.nx, d.nu, h->beta, h->beta_f, h->g, h->gf_raw, h->c, nullptr, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 0, h->ct_part, h->cost_tube};
     hipLaunchKernelGGL(k_tighten, dim3(h->B), dim3(128), 0, h->st, ta);
     HIPCHK(hipEventRecord(h->ev[2], h->st));
     HIPCHK(hipStreamSynchronize(h->st));

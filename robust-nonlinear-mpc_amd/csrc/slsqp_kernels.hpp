@@ -1012,6 +1012,7 @@ struct SweepArgs {
     Costs cst;
     double *K;                 // (B,N,N+1,NU,NX)
     double *beta, *beta_f;     // (B,N,N,NI) (B,N+1,NIF)
+    double *ct_part;           // (B,N+1) per-column part of cost_tube^2 = || blkdiag(Q_reg..,Q_reg_f,R_reg..) [Phi_x;Phi_u] ||_F^2 (util/SLS.py:38-46)
     double eps;
 };
 
@@ -1176,6 +1177,7 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
     wla::wsync();
     double *Pc = sPhi, *Pn = sPhi2;
     double rK[RB];
+    double ctube = 0.0;
     auto fetch2 = [&](int k) {
         const double *Ak = gA + (size_t)k * NX * NX, *Bk = gB + (size_t)k * NX * NU;
         const double *Kg = gK + ((size_t)k * (N + 1) + j) * NU * NX;
@@ -1221,6 +1223,8 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
             }
             s = s + __shfl(s, lane + NZ) + __shfl(s, lane + 2 * NZ);
             if (lane < NZ) {
+                const double wr = (lane < NX) ? a.cst.Qregd[lane] : a.cst.Rregd[lane - NX];
+                ctube = fma(wr * wr, s, ctube);       // weighted row norms: this column's share of cost_tube^2
                 s = fmax(s, a.eps);
                 double *bo = beta + ((size_t)k * N + j) * NI;
                 bo[lane] = s; bo[NZ + lane] = s;
@@ -1239,9 +1243,12 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; w++) s = fma(row[w], row[w], s);
+        ctube = fma(a.cst.Qregfd[lane] * a.cst.Qregfd[lane], s, ctube);
         s = fmax(s, a.eps);
         beta_f[j * NIF + lane] = s; beta_f[j * NIF + NX + lane] = s;
     }
+    ctube = wla::wave_sum(ctube);
+    if (lane == 0 && a.ct_part) a.ct_part[(size_t)b * (N + 1) + j] = ctube;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1253,6 +1260,7 @@ struct TightenArgs {
     const int *run;
     double *backoff, *backoff_f, *backoff_x, *backoff_u, *ubg;
     int write_ubg;
+    const double *ct_part; double *cost_tube;   // (B,N+1) -> (B): cost_tube = sqrt(sum over columns)
 };
 __global__ void k_tighten(TightenArgs a) {
     const int b = blockIdx.x;
@@ -1280,6 +1288,11 @@ __global__ void k_tighten(TightenArgs a) {
     }
     if (a.write_ubg)
         for (int o = threadIdx.x; o < N * NX; o += blockDim.x) ub[(o / NX) * SR + (o % NX)] = -a.c[(size_t)b * N * NX + o];
+    if (threadIdx.x == 0 && a.ct_part) {
+        double acc = 0.0;
+        for (int j = 0; j <= N; j++) acc += a.ct_part[(size_t)b * (N + 1) + j];
+        a.cost_tube[b] = sqrt(acc);
+    }
 }
 
 // initialize_backoff (fast_SLS_jit.py:444-454)

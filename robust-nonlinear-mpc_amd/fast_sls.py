@@ -229,7 +229,8 @@ class BatchedFastSLS:
             status=self.get("status", (), np.int32),
             qp_iters=self.get("qp_iters", (), np.int32),
             cost_nominal=self.get("cost_nominal", ()),
-            cost_tube=np.full(B, np.nan), cost=np.full(B, np.nan),
+            cost_tube=np.full(B, np.nan), cost=np.full(B, np.nan),     # NaN in the reference's dict too (fast_SLS_jit.py:619-620)
+            cost_tube_value=self.get("cost_tube", ()),                # what the reference computes and prints (:540-544, SLS.eval_cost)
             primal_x=primal_x, primal_u=primal_u, primal_vec=pv, dual_vec=dv, dual_mu=dual_mu, dual_mu_f=dual_mu_f,
             eta=self.get("eta", (N, N, ni)), eta_f=self.get("eta_f", (N + 1, nif)),
             K=K, K_mat=K.transpose(0, 1, 3, 2, 4).reshape(B, N * nu, (N + 1) * nx),
@@ -279,7 +280,7 @@ class BatchedFastSLS:
         bo = np.empty((B, N, m.ni))
         bof = np.empty((B, m.ni_f))
         L.check(self.lib.slsqp_sweep(self.h, _ptr(eta), _ptr(eta_f), _ptr(K), _ptr(beta), _ptr(beta_f), _ptr(bo), _ptr(bof), L.HOST))
-        return dict(K=K, beta=beta, beta_f=beta_f, backoff=bo, backoff_f=bof)
+        return dict(K=K, beta=beta, beta_f=beta_f, backoff=bo, backoff_f=bof, cost_tube_value=self.get("cost_tube", ()))
 
 
 class fast_SLS(BatchedFastSLS):

@@ -49,6 +49,20 @@ def test_sweep_vs_reference_golden(case):
     assert relerr(out["backoff"][0], g["backoff"]) < 1e-9
     assert relerr(out["backoff_f"][0], g["backoff_f"]) < 1e-9
     assert relerr(out["K"][1], g["K"]) > 1e-6  # perturbed instance really differs
+    # cost_tube = || blkdiag(Q_reg x N, Q_reg_f, R_reg x N) [Phi_x; Phi_u] ||_F (util/SLS.py:38-46, fast_SLS_jit.py:540-544), from the
+    # reference's own Phi where the fixture holds it, else from its block Frobenius norms (the regularisers are multiples of I)
+    want = None
+    if "Phi_x" in g:
+        qd, rd, qfd = np.diag(g["Q_reg"]), np.diag(g["R_reg"]), np.diag(g["Q_reg_f"])
+        Px, Pu = g["Phi_x"], g["Phi_u"]
+        want = np.sqrt(sum((((qd if k < N else qfd)[:, None] * Px[k, j]) ** 2).sum() for k in range(N + 1) for j in range(N + 1))
+                       + sum(((rd[:, None] * Pu[k, j]) ** 2).sum() for k in range(N) for j in range(N + 1)))
+    else:
+        q, r, qf = g["Q_reg"][0, 0], g["R_reg"][0, 0], g["Q_reg_f"][0, 0]
+        if np.allclose(g["Q_reg"], q * np.eye(m.nx)) and np.allclose(g["R_reg"], r * np.eye(m.nu)) and np.allclose(g["Q_reg_f"], qf * np.eye(m.nx)):
+            want = np.sqrt(((q * g["Phix_fro"][:N]) ** 2).sum() + ((qf * g["Phix_fro"][N]) ** 2).sum() + ((r * g["Phiu_fro"]) ** 2).sum())
+    if want is not None:
+        assert abs(out["cost_tube_value"][0] - want) < 1e-9 * max(1.0, want)
 
 
 @pytest.mark.parametrize("model,amps", [("pendulum", (0.2, 1.0)), ("quadrotor", (0.2, 1.0, 2.0)), ("rocket", (0.2, 1.0))])

@@ -152,7 +152,8 @@ def main():
     n_sl = len(dev.slices)
     value = qps_per_step * world * args.steps / dt
     out = {
-        "metric": "QP solves/sec (whole node), rockETH N=20 batch=4096 RTI MPC step", "value": value, "unit": "QP solves/s",
+        "metric": ("QP solves/sec (whole node), rockETH N=20 batch=4096 RTI MPC step" if (args.model, B) == ("rocket", 4096)
+                   else f"QP solves/sec (whole node), {args.model} N={N} batch={B} RTI MPC step"), "value": value, "unit": "QP solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 0 else "f32 factorisation + f64 residuals (mixed)", "data": "synthetic",
         "config": {"workload": f"{args.model} N={N} batch={B}/GPU, fast-SLS RTI step (rti_steps=1: 2 QP solves + 1 SLS sweep per instance)",

@@ -9,7 +9,7 @@ batch = make_batch("rocket", os.path.join(ROOT, "tests", "golden", "sweep_rocket
 m, N = batch["model"], batch["N"]
 f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=B)
 f.set_rti_steps(1); f.opts.warm_start = 0
-f.opts.warm_rounds = int(os.environ.get("QP_WARM_ROUNDS", "3"))
+f.opts.warm_rounds = int(os.environ.get("QP_WARM_ROUNDS", "4"))
 dev = DeviceBatch(f, batch)
 dev.step(); dev.step()
 kk = f.get("kkt", (8,)); it = f.get("qp_iters", (), np.int32)

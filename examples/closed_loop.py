@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     m = get_model(a.model)
-    N = a.N or {"pendulum": 10, "quadrotor": 20, "rocket": 15}[a.model]      # the scripts' horizons
+    N = a.N or 15                                                            # the scripts' default horizon (main_*_robust_closed_loop.py: N = 15)
     steps = a.steps or m.extra.get("sim_steps", 30)
     B = a.runs
     rng = np.random.default_rng(0)

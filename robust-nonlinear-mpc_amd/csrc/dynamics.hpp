@@ -38,6 +38,20 @@ DYN_HD Dual msin(Dual a) { return Dual(sin(a.v), cos(a.v) * a.d); }
 DYN_HD Dual mcos(Dual a) { return Dual(cos(a.v), -sin(a.v) * a.d); }
 DYN_HD Dual msqrt(Dual a) { const double s = sqrt(a.v); return Dual(s, 0.5 * a.d / s); }
 DYN_HD Dual matan(Dual a) { return Dual(atan(a.v), a.d / (1.0 + a.v * a.v)); }
+// sine and cosine of one argument together: one range reduction instead of two (double), or instead of four (Dual: msin and mcos
+// each need both)
+DYN_HD void msincos(double a, double &s, double &c) {
+#ifdef __HIP_DEVICE_COMPILE__
+    sincos(a, &s, &c);
+#else
+    s = sin(a); c = cos(a);
+#endif
+}
+DYN_HD void msincos(Dual a, Dual &s, Dual &c) {
+    double sv, cv;
+    msincos(a.v, sv, cv);
+    s = Dual(sv, cv * a.d); c = Dual(cv, -sv * a.d);
+}
 DYN_HD double msin(double a) { return sin(a); }
 DYN_HD double mcos(double a) { return cos(a); }
 DYN_HD double msqrt(double a) { return sqrt(a); }
@@ -53,7 +67,8 @@ template <typename T>
 DYN_HD void ode_pendulum(const T *X, const T *U, T *dX) {
     const T xd = X[1], th = X[2], thd = X[3], u = U[0];
     const double m1 = 1.0, m2 = 0.1, l = 0.5, g = 9.81;
-    const T s = msin(th), c = mcos(th);
+    T s, c;
+    msincos(th, s, c);
     const T den = T(m1) + T(m2) * (T(1.0) - c * c);
     const T xdd = (u + T(m2 * l) * thd * thd * s - T(m2 * g) * s * c) / den;
     const T thdd = (-u * c - T(m2 * l) * thd * thd * s * c + T((m1 + m2) * g) * s) / (T(l) * den);
@@ -96,12 +111,14 @@ DYN_HD void ode_quadrotor(const T *X, const T *U, T *dX) {
 }
 
 template <typename T>
-DYN_HD T gimbal_angle(T servo, T tilt) {   // rocket.py:246-254
+DYN_HD T gimbal_angle(T servo, T cos_tilt) {   // rocket.py:246-254; takes cos(tilt_axis_angle): the caller has it already
     const double a = 5.0, b = 35.2, c = 33.0, d = 28.0, e = 35.2;
-    const T iv1 = T(d) + T(a) * mcos(servo);
-    const T iv2 = T(e) - T(a) * msin(servo);
+    T ss, cs;
+    msincos(servo, ss, cs);
+    const T iv1 = T(d) + T(a) * cs;
+    const T iv2 = T(e) - T(a) * ss;
     const T u = T(b * b - c * c) - iv1 * iv1 - iv2 * iv2;
-    const T v = T(2.0 * c) * mcos(tilt) * iv2;
+    const T v = T(2.0 * c) * cos_tilt * iv2;
     const T w = T(-2.0 * c) * iv1;
     const T iv3 = w * w + v * v - u * u;
     return T(2.0) * matan((v - msqrt(iv3)) / (u + w));
@@ -113,9 +130,12 @@ DYN_HD void ode_rocket(const T *X, const T *U, T *dX) {
     const T qw = X[6], qx = X[7], qy = X[8], qz = X[9], wx = X[10], wy = X[11], wz = X[12];
     const T thrust = X[13] + T(hover), torque_x = X[14], sa1 = X[15], sa2 = X[16];
     const T thrust_in = U[0] + T(hover), torque_in = U[1], sa1_in = U[2], sa2_in = U[3];
-    const T g1 = gimbal_angle(sa1, T(0.0));
-    const T g2 = gimbal_angle(sa2, g1);
-    const T Bx = -thrust * msin(g1) * mcos(g2), By = thrust * msin(g2), Bz = thrust * mcos(g1) * mcos(g2);
+    T s1, c1, s2, c2;
+    const T g1 = gimbal_angle(sa1, T(1.0));
+    msincos(g1, s1, c1);
+    const T g2 = gimbal_angle(sa2, c1);
+    msincos(g2, s2, c2);
+    const T Bx = -thrust * s1 * c2, By = thrust * s2, Bz = thrust * c1 * c2;
     T ax, ay, az;
     rot_apply(qw, qx, qy, qz, Bx, By, Bz, ax, ay, az);
     dX[0] = X[3]; dX[1] = X[4]; dX[2] = X[5];

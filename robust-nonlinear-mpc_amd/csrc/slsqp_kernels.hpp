@@ -1325,7 +1325,7 @@ struct LinArgs {
     const int *run;   // (B) 1 = linearise this instance (NULL = all)
 };
 template <int MODEL>
-__global__ void k_lin_jac(LinArgs a) {
+__global__ __launch_bounds__(128) void k_lin_jac(LinArgs a) {
     constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU, NZ = NX + NU;
     const size_t tot = (size_t)a.B * a.N * NZ;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {

@@ -142,6 +142,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     fwd_total_ms, fwd_launches, inst_sweeps, mx_retries = dev.kernel_timing()
+    fact_sweeps = dev.fwd_factor_sweeps
     if world > 1:
         tmax = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -184,6 +185,12 @@ def main():
                                         "achieved_GBps": QP_BYTES[args.model] * B / n_sl / (qp_ms * 1e-3) / 1e9,
                                         "note": "one solve call = one slice; slices run concurrently, so these times overlap"},
                            "last_qp_block_solves_per_instance": {"factorising": float(kk[:, 6].mean()), "all": float(kk[:, 7].mean())},
+                           # second ceiling: fp64 work of the timed region / wall time against the vector = matrix fp64 peak.  Per instance
+                           # sweep of N stages: 28.6 kflop per factorising stage, 2 kflop per forward / backward substitution stage;
+                           # SLS sweep 9.0 Mflop per rocket instance (scaled with nx^3 for the other plants)
+                           "fp64": {"achieved_TFLOPs": (fact_sweeps * N * 28.6e3 * (m.nx / 17.0) ** 3 + (2 * inst_sweeps - fact_sweeps) * N * 2.0e3 * (m.nx / 17.0) ** 2
+                                                        + args.steps * B * 9.0e6 * (m.nx / 17.0) ** 3 * (N / 20.0) ** 2) / dt / 1e12,
+                                    "peak_TFLOPs": 78.6, "note": "vector fp64 peak = matrix fp64 peak on MI355X (BASELINE.md, AMD public figure)"},
                            "sweep_avg_launch_ms": sw_ms, "slice_gpu_ms_per_step": [round(a["total"] / args.steps, 2) for a in acc]}
         if n_sl > 1:
             # the same kernel with the whole batch in ONE slice (no concurrent launches), two extra steps outside the timed region: with

@@ -166,8 +166,8 @@ int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta_f, double 
    measured with HIP events on the handle's stream: [0] total, [1] QP kernel(s), [2] sweep kernel, [3] other */
 int slsqp_last_timing(slsqp_handle *h, double *ms4);
 /* accumulated since the last call: [0] total ms of k_ne_fwd launches (HIP events around each launch, handle's stream),
-   [1] number of launches, [2] instances re-solved in fp64 after a mixed-precision attempt, [3] instance-sweeps those launches did
-   (device counter); resets the accumulators.  out must hold 4 doubles. */
+   [1] number of launches, [2] instances re-solved in fp64 after a mixed-precision attempt, [3] instance-sweeps those launches did,
+   [4] how many of them factorised (device counters); resets the accumulators.  out must hold 5 doubles. */
 int slsqp_kernel_timing(slsqp_handle *h, double *out4);
 void *slsqp_stream(slsqp_handle *h); /* hipStream_t, for callers that share device buffers */
 

@@ -123,7 +123,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(&h->retry, B); h->mx_retry = 0; h->mx_retry_total = 0;
     rc |= dalloc(&h->nom_st, B * 12); rc |= dalloc(&h->nom_need_lin, B); rc |= dalloc(&h->nom_status, B); rc |= dalloc(&h->nom_iters, B);
     rc |= dalloc(&h->mapA, (size_t)N * nx * nx); rc |= dalloc(&h->mapB, (size_t)N * nx * nu);
-    rc |= dalloc(&h->inst_launches, (size_t)1); rc |= dalloc(&h->ct_part, B * (N + 1)); rc |= dalloc(&h->cost_tube, B);
+    rc |= dalloc(&h->inst_launches, (size_t)2); rc |= dalloc(&h->ct_part, B * (N + 1)); rc |= dalloc(&h->cost_tube, B);
     h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
@@ -485,11 +485,11 @@ extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms4) {
     return 0;
 }
 extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out3) {
-    unsigned long long il = 0;
+    unsigned long long il[2] = {0, 0};
     hipSetDevice(h->dev);
-    hipMemcpy(&il, h->inst_launches, sizeof(il), hipMemcpyDeviceToHost);
+    hipMemcpy(il, h->inst_launches, sizeof(il), hipMemcpyDeviceToHost);
     hipMemset(h->inst_launches, 0, sizeof(il));
-    out3[0] = h->t_fwd; out3[1] = (double)h->n_fwd; out3[2] = (double)h->mx_retry_total; out3[3] = (double)il;
+    out3[0] = h->t_fwd; out3[1] = (double)h->n_fwd; out3[2] = (double)h->mx_retry_total; out3[3] = (double)il[0]; out3[4] = (double)il[1];
     h->t_fwd = 0; h->n_fwd = 0; h->mx_retry_total = 0;
     return 0;
 }

@@ -78,7 +78,7 @@ struct QpArgs {
     int warm;                 // 1: try an active-set polish from the previous solution of each instance first
     const double *prox;       // per-instance proximal weight added to the diagonal cost (element b * prox_stride), or NULL
     int prox_stride;
-    unsigned long long *inst_launches;   // += 1 per instance forward sweep (roofline accounting of bench.py)
+    unsigned long long *inst_launches;   // [0] += 1 per instance forward sweep, [1] += 1 per factorising one (roofline accounting of bench.py)
     int n_refine;             // refinement solves per polish (1 in fp64, 3 with fp32 factorisations)
     double early_ctol;        // tolerance (relative to max(1,|q|inf)) of the look at the un-refined polish solve: its accuracy class
 };
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
 #endif
     // in the refinement solves the right-hand side is E zn - e (+ a vanishing term): the dynamics residual of the polished point
     if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
-    if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
+    if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { atomicAdd(a.inst_launches + 1, 1ULL); st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
 }
 
 template <int NX, int NU>
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(64, QP_MX_WAVES_PER_SIMD) void k_ne_fwd_mx(QpArgs a
     double bmax = 0.0;
     const int f = ne_forward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane, &bmax);
     if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
-    if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
+    if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { atomicAdd(a.inst_launches + 1, 1ULL); st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
 }
 template <int NX, int NU>
 __global__ __launch_bounds__(64) void k_ne_bwd_phase_mx(QpArgs a) {

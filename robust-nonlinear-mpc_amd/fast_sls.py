@@ -198,10 +198,11 @@ class BatchedFastSLS:
 
     def kernel_timing(self):
         """(total ms, launches) of the dominant kernel k_ne_fwd since the last call (HIP events on the handle's stream)."""
-        t = np.zeros(4)
+        t = np.zeros(5)
         self.lib.slsqp_kernel_timing(self.h, _ptr(t))
         self.mx_retries = int(t[2])
-        self.fwd_instance_sweeps = int(t[3])   # instance forward sweeps those launches did      # instances re-solved in fp64 after a mixed-precision attempt (opts.precision = 1)
+        self.fwd_instance_sweeps = int(t[3])   # instance forward sweeps those launches did
+        self.fwd_factor_sweeps = int(t[4])     # ... of which factorising      # instances re-solved in fp64 after a mixed-precision attempt (opts.precision = 1)
         return t[0], int(t[1])
 
     def solve(self, x0, fetch=True):
@@ -407,9 +408,11 @@ class SlicedDeviceBatch:
     def kernel_timing(self):
         """Summed over the slices: (total ms of k_ne_fwd launches, launches, instance sweeps, fp64 re-solves)."""
         tot = [0.0, 0, 0, 0]
+        self.fwd_factor_sweeps = 0
         for f in self.solvers:
             ms, n = f.kernel_timing()
             tot[0] += ms; tot[1] += n; tot[2] += f.fwd_instance_sweeps; tot[3] += f.mx_retries
+            self.fwd_factor_sweeps += f.fwd_factor_sweeps
         return tuple(tot)
 
     def close(self):

@@ -32,6 +32,10 @@ constexpr int ST_INIT = -1;
 #ifndef NE_MFMA
 #define NE_MFMA 1
 #endif
+// NE_GJ_MFMA: the SPD inverse of the factor sweep as a 4x4-block Gauss-Jordan sweep on the matrix core (wla::spd_inv_blk4_mfma)
+#ifndef NE_GJ_MFMA
+#define NE_GJ_MFMA 0
+#endif
 
 struct Costs {  // batch-constant diagonal weights (device pointers)
     const double *Qd, *Rd, *Qfd;        // diag of Q, R, Qf (P = 2*blkdiag)
@@ -180,6 +184,10 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             else wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
             wla::wsync();
             STAMP(3);
+#if NE_GJ_MFMA
+            if constexpr (Ld::MFMA) fail |= wla::spd_inv_blk4_mfma<NX>(sY, NX, Lcur, NX, lane);
+            else
+#endif
             fail |= wla::spd_inv_gj<NX>(sY, NX, Lcur, NX, (double *)nullptr, lane);
             STAMP(4);
             double *Lg = g.Linv + (size_t)k * MM;

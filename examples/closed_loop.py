@@ -47,7 +47,7 @@ def main():
         W = np.stack([disturbance_stream(s, steps, m.nx) for s in range(B)], axis=1)   # seed 0 = the script's stream
     cl = ClosedLoopMPC(m, N, B)
     t0 = time.perf_counter()
-    out = cl.run_on_device(x0, steps, W, solve_nominal=True)
+    out = cl.run_on_device(x0, steps, W, solve_nominal=True, continuation=2 if a.model == "rocket" else 1)
     dt = time.perf_counter() - t0
     dist0 = np.linalg.norm(out["state_trajectory"][:, :, 0] - m.x_ref, axis=1).mean()
     dist1 = np.linalg.norm(out["state_trajectory"][:, :, -1] - m.x_ref, axis=1).mean()

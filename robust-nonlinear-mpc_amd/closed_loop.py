@@ -37,21 +37,29 @@ class ClosedLoopMPC:
     def close(self):
         self.f.close()
 
-    def reset(self, x_meas, X_nom=None, U_nom=None, u_init=None, solve_nominal=False, max_qp=120, tol=1e-7, rho=1e3):
+    def reset(self, x_meas, X_nom=None, U_nom=None, u_init=None, solve_nominal=False, max_qp=120, tol=1e-7, rho=1e3, continuation=1):
         """x_meas (B,nx).  X_nom (B,N+1,nx), U_nom (B,N,nu) optional initial nominal; else roll-out under `u_init` (default: the
         model's neutral input).  solve_nominal=True then solves the nominal NLP from that guess on the GPU (the role IPOPT has in
-        SCP_SLS.solve_nominal_trajectory, SCP_SLS_jit.py:161-188); per-instance outcome in self.nlp_status (0 = KKT point found)."""
+        SCP_SLS.solve_nominal_trajectory, SCP_SLS_jit.py:161-188); per-instance outcome in self.nlp_status (0 = KKT point found).
+        continuation=K > 1 (far-away states): the NLP is solved for x_ref + s (x_meas - x_ref), s = 1/K, 2/K, ..., 1, each stage from the
+        previous stage's trajectory (the initial-state constraint is damped like the others, so a stage moves x_0 gradually)."""
         f, m = self.f, self.m
         x_meas = _c(x_meas)
         assert x_meas.shape == (self.B, m.nx)
         Xn = None if X_nom is None else _c(X_nom)
         Un = None if U_nom is None else _c(U_nom)
         ui = _c(m.u_ref if u_init is None else u_init)
-        L.check(f.lib.slsqp_cl_init(f.h, _ptr(x_meas), _ptr(Xn), _ptr(Un), _ptr(ui), L.HOST))
+        K = max(1, int(continuation)) if solve_nominal and Xn is None else 1
+        x_first = x_meas if K == 1 else _c(m.x_ref + (x_meas - m.x_ref) / K)
+        L.check(f.lib.slsqp_cl_init(f.h, _ptr(x_first), _ptr(Xn), _ptr(Un), _ptr(ui), L.HOST))
         self.steps_done = 0
         self.nlp_status = None
         if solve_nominal:
             L.check(f.lib.slsqp_nominal_solve(f.h, int(max_qp), float(tol), float(rho), C.byref(f.opts)))
+            for k in range(2, K + 1):
+                xs = _c(m.x_ref + (x_meas - m.x_ref) * (k / K))
+                L.check(f.lib.slsqp_set(f.h, b"x_meas", _ptr(xs), L.HOST))
+                L.check(f.lib.slsqp_nominal_solve(f.h, int(max_qp), float(tol), float(rho), C.byref(f.opts)))
             self.nlp_status = f.get("nlp_status", (), np.int32)
             self.nlp_iterations = f.get("nlp_iterations", (), np.int32)
             self.nlp_info = f.get("nlp_info", (12,))
@@ -74,12 +82,12 @@ class ClosedLoopMPC:
             t_qp_ms=f.timing_ms()["qp"], t_riccati_ms=f.timing_ms()["sweep"],
         )
 
-    def run_on_device(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False):
+    def run_on_device(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False, continuation=1):
         """Same result as run(), but the per-step records stay in device buffers (slsqp_cl_log) and are read back once at the end: the only
         host -> device traffic per MPC step is the disturbance sample (B,nx)."""
         f, m, N, B = self.f, self.m, self.N, self.B
         L.check(f.lib.slsqp_cl_log(f.h, int(steps)))
-        self.reset(x0, X_nom, U_nom, solve_nominal=solve_nominal)
+        self.reset(x0, X_nom, U_nom, solve_nominal=solve_nominal, continuation=continuation)
         t_qp, t_ric = np.zeros((steps, 1)), np.zeros((steps, 1))
         for i in range(steps):
             self.step(None if W is None else W[i], fetch=False)

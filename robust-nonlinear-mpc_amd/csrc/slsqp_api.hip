@@ -632,7 +632,7 @@ extern "C" int slsqp_nominal_solve(slsqp_handle *h, int max_qp, double tol, doub
     hipLaunchKernelGGL(k_nom_init, dim3(gbi), dim3(256), 0, h->st, B, h->nom_st, active, h->nom_need_lin, h->nom_status, h->nom_iters, 1.0, 0.5);
     ClArgs ca = cl_args(h, nullptr);
     NomArgs na;
-    na.B = B; na.N = d.N; na.Xn = h->Xn; na.Un = h->Un; na.primal = h->primal; na.qp_status = h->status; na.g_raw = h->g_raw; na.gf_raw = h->gf_raw;
+    na.B = B; na.N = d.N; na.Xn = h->Xn; na.Un = h->Un; na.xmeas = h->xmeas; na.primal = h->primal; na.qp_status = h->status; na.g_raw = h->g_raw; na.gf_raw = h->gf_raw;
     na.cst = costs_of(h); na.st = h->nom_st; na.active = active; na.need_lin = h->nom_need_lin; na.status = h->nom_status; na.iters = h->nom_iters;
     na.n_active = h->counter + 2; na.rho = rho; na.tol = tol; na.w_max = 1e8;
     auto eval = [&](int mode) {
@@ -647,8 +647,7 @@ extern "C" int slsqp_nominal_solve(slsqp_handle *h, int max_qp, double tol, doub
         if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, h->nom_need_lin)) return -1;     // accepted instances only; the others re-solve
         NomBoundsArgs ba{B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->nom_st, active, h->ubg, h->lbg, 1e-10};
         hipLaunchKernelGGL(k_nom_bounds, dim3(1024), dim3(256), 0, h->st, ba);
-        hipLaunchKernelGGL(k_cl_x0arg, dim3(64), dim3(256), 0, h->st, ca);                   // x0arg = x_nom0 - x_meas
-        hipLaunchKernelGGL(k_negate, dim3((B * d.nx + 255) / 256), dim3(256), 0, h->st, h->x0arg, h->x0val, B * d.nx);
+        hipLaunchKernelGGL(k_nom_x0, dim3((B * d.nx + 255) / 256), dim3(256), 0, h->st, B, d.N, d.nx, h->Xn, h->xmeas, h->nom_st, h->x0val);
         HIPCHK(hipEventRecord(h->ev[6], h->st));
         if (launch_qp(h, active, &o, it > 0 ? 1 : 0, h->nom_st /* S[0] = w: stride 12 */)) return -1;
         HIPCHK(hipEventRecord(h->ev[7], h->st));

@@ -1516,6 +1516,7 @@ __global__ void k_cl_rollout(ClArgs a) {
 struct NomArgs {
     int B, N;
     double *Xn, *Un;
+    const double *xmeas;       // (B,NX): x_0 = x_meas is a constraint of the NLP like the dynamics: |X_0 - x_meas|_1 counts as defect
     const double *primal;
     const int *qp_status;
     const double *g_raw, *gf_raw;
@@ -1569,6 +1570,7 @@ __global__ __launch_bounds__(128) void k_nom_eval(NomArgs a) {
         dyn::ddyn<MODEL, double>(x, u, xp);
         for (int i = 0; i < NX; i++) c += fabs(xp[i] - (X[(k + 1) * NX + i] + (trial ? d[(k + 1) * NZ + i] : 0.0)));
     }
+    if (t < NX) c += fabs(X[t] + (trial ? d[t] : 0.0) - a.xmeas[(size_t)b * NX + t]);
     f = block_sum128(f, red); v = block_sum128(v, red); c = block_sum128(c, red); dm = block_max128(dm, red);
     if (t == 0) {
         int dec = 0;   // 0 retry the QP (same linearisation), 1 step accepted, 2 converged, 3 failed
@@ -1635,6 +1637,13 @@ __global__ void k_nom_bounds(NomBoundsArgs a) {
         } else { const double gv = a.gN[(size_t)b * a.NIF + (r - a.N * SR)]; u = gv + kap * fmax(-gv, 0.0) + a.eps; l = -1e20; }
         a.ubg[idx] = u; a.lbg[idx] = l;
     }
+}
+// pin of the initialiser's QP: d_x0 = tau (x_meas - X_0), the same fraction of this constraint's violation as of the others
+__global__ void k_nom_x0(int B, int N, int NX, const double *Xn, const double *xmeas, const double *st, double *x0val) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * NX) return;
+    const int b = t / NX, i = t % NX;
+    x0val[t] = (1.0 - st[(size_t)b * 12 + 1]) * (xmeas[t] - Xn[(size_t)b * (N + 1) * NX + i]);
 }
 __global__ void k_nom_init(int B, double *st, int *active, int *need_lin, int *status, int *iters, double w0, double kappa0) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -15,18 +15,18 @@ def disturbance_stream(seed, steps, nx):
     return np.stack([2.0 * rs.rand(nx) - 1.0 for _ in range(steps)])
 
 
-def _run_slice(model, N, seeds, steps, x0, device, noise, solve_nominal):
+def _run_slice(model, N, seeds, steps, x0, device, noise, solve_nominal, continuation=1):
     B = len(seeds)
     W = np.stack([disturbance_stream(s, steps, model.nx) for s in seeds], axis=1) if noise else None   # (steps, B, nx)
     cl = ClosedLoopMPC(model, N, B, device=device)
-    out = cl.run_on_device(np.tile(np.asarray(x0, dtype=float), (B, 1)), steps, W, solve_nominal=solve_nominal)
+    out = cl.run_on_device(np.tile(np.asarray(x0, dtype=float), (B, 1)), steps, W, solve_nominal=solve_nominal, continuation=continuation)
     if cl.nlp_status is not None:
         out.update(nlp_status=cl.nlp_status, nlp_iterations=cl.nlp_iterations)
     cl.close()
     return out
 
 
-def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise=True, gather=True, solve_nominal=False, slices=1):
+def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise=True, gather=True, solve_nominal=False, slices=1, continuation=1):
     """slices > 1: the rank's seeds are cut into that many independent slices, each with its own handle (HIP stream) and host thread
     (as in fast_sls.SlicedDeviceBatch): results are bit-identical, the slices' solver tails overlap each other's bulk launches."""
     import threading
@@ -41,7 +41,7 @@ def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise
 
     def work(k):
         try:
-            parts[k] = _run_slice(model, N, mine[cuts[k][0]:cuts[k][1]], steps, x0, device, noise, solve_nominal)
+            parts[k] = _run_slice(model, N, mine[cuts[k][0]:cuts[k][1]], steps, x0, device, noise, solve_nominal, continuation)
         except Exception as e:
             err.append(e)
 

@@ -506,6 +506,31 @@ def test_nominal_initialiser_reaches_nlp_kkt_point(model, N, amp):
     cl.close()
 
 
+def test_script_rocket_x0_runs_closed_loop_from_the_gpu_initialiser():
+    """The rocket script's own initial state (expe/main_rocket_robust_closed_loop.py:110-126: an attitude 75 degrees off, servos deflected) is
+    out of reach of a plain roll-out.  With the initial-state continuation of the nominal initialiser the first nominal is feasible (dynamics
+    and box to 1e-6 / 1e-8, checked with the CPU dynamics) and the script's closed loop (rti = 1, one fast-SLS step, N = 15, seed-0 noise) solves
+    every MPC step.  IPOPT's own nominal is not available offline: parity unpinned for the trajectory values."""
+    from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
+    from problems import host_ddyn
+    m = get_model("rocket")
+    N, B, steps = 15, 2, 5
+    x0 = np.tile(m.extra["x0"], (B, 1))
+    W = np.stack([disturbance_stream(s, steps, m.nx) for s in range(B)], axis=1)
+    cl = ClosedLoopMPC(m, N, B)
+    cl.reset(x0, solve_nominal=True, continuation=2)
+    X, U = cl.f.get("nominal_x", (N + 1, m.nx)), cl.f.get("nominal_u", (N, m.nu))
+    for b in range(B):
+        assert np.abs(X[b, 0] - x0[b]).max() < 1e-9
+        defect = max(np.abs(host_ddyn(m.model_id, X[b, k], U[b, k]) - X[b, k + 1]).max() for k in range(N))
+        assert defect < 1e-6, defect
+        assert (X[b, 1:] <= m.x_ub + 1e-8).all() and (X[b, 1:] >= m.x_lb - 1e-8).all()
+        assert (U[b] <= m.u_ub + 1e-8).all() and (U[b] >= m.u_lb - 1e-8).all()
+    ok = [cl.step(W[i])["success"] for i in range(steps)]
+    cl.close()
+    assert np.all(ok)
+
+
 def test_monte_carlo_seeds_and_npz_keys(tmp_path):
     """Seeded closed-loop Monte-Carlo (config 5 shape, tiny): distinct seeds give distinct trajectories, seed streams are
     reproducible run to run, and the npz written for one instance carries the reference's key set (main_rocket...:189-206)."""

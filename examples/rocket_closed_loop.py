@@ -6,7 +6,8 @@ reference's expe/main_rocket_robust_closed_loop.py `generate()` (same weights, E
 
 The reference starts from an IPOPT nominal trajectory (SCP_SLS.solve_nominal_trajectory); here `--init sqp` (default) solves the same
 nominal NLP on the GPU (slsqp_nominal_solve, trust-region SCP from a hover roll-out) and `--init rollout` uses the bare roll-out.
-`--x0-scale s` starts from x_ref + s (x0_script - x_ref).
+`--x0-scale s` starts from x_ref + s (x0_script - x_ref); the script's own x0 (s = 1, the default) needs the initial-state continuation
+(`--continuation 2`, default).
 """
 import argparse
 import os

@@ -1577,7 +1577,7 @@ __global__ __launch_bounds__(128) void k_nom_eval(NomArgs a) {
         double w = S[0], kap = S[1], kap0 = S[2];
         const double f0 = S[3], c0 = S[4], v0 = S[5];
         if (!trial) {
-            S[3] = f; S[4] = c; S[5] = v; S[1] = (v > 1e-9 || c > 1e-6) ? kap0 : 0.0;
+            S[3] = f; S[4] = c; S[5] = v; S[1] = (v > 1e-7 || c > 1e-6) ? kap0 : 0.0;
             dec = -1;
         } else {
             const int qs = a.qp_status[b];
@@ -1589,14 +1589,14 @@ __global__ __launch_bounds__(128) void k_nom_eval(NomArgs a) {
                 const double pred = phi0 - (f + a.rho * kap * (v0 + c0));     // linearised model: violation shrinks to kappa * (v0 + c0)
                 const double act = phi0 - (f + a.rho * (c + v));
                 r = pred > 0.0 ? act / pred : -1.0;
-                if (pred <= 1e-12 * fmax(1.0, fabs(phi0)) || dm < a.tol) dec = (v0 < 1e-9 && c0 < 1e-7) ? 2 : 1;
+                if (pred <= 1e-12 * fmax(1.0, fabs(phi0)) || dm < a.tol) dec = (v0 < 1e-7 && c0 < 1e-7)   /* l1 sums; the QP's own 1e-10 pads on every bound add up to ~1e-9 */ ? 2 : 1;
                 else if (r < 0.1) { w *= 4.0; kap = 1.0 - (1.0 - kap) / 3.0; dec = (w > a.w_max) ? 3 : 0; }
                 else { dec = 1; kap0 = kap; if (r > 0.7) { w = fmax(w / 3.0, 1e-6); kap0 = kap > 0.01 ? kap / 3.0 : 0.0; } }
             }
             S[6] = r; S[7] = dm;
             if (dec == 1 || dec == 2) {
                 S[3] = f; S[4] = c; S[5] = v;
-                kap = (v > 1e-9 || c > 1e-6) ? kap0 : 0.0;
+                kap = (v > 1e-7 || c > 1e-6) ? kap0 : 0.0;
                 a.iters[b] += 1;
             }
             S[0] = w; S[1] = kap; S[2] = kap0;

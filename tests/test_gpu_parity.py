@@ -508,8 +508,8 @@ def test_nominal_initialiser_reaches_nlp_kkt_point(model, N, amp):
 
 def test_script_rocket_x0_runs_closed_loop_from_the_gpu_initialiser():
     """The rocket script's own initial state (expe/main_rocket_robust_closed_loop.py:110-126: an attitude 75 degrees off, servos deflected) is
-    out of reach of a plain roll-out.  With the initial-state continuation of the nominal initialiser the first nominal is feasible (dynamics
-    and box to 1e-6 / 1e-8, checked with the CPU dynamics) and the script's closed loop (rti = 1, one fast-SLS step, N = 15, seed-0 noise) solves
+    out of reach of a plain roll-out.  With the initial-state continuation of the nominal initialiser the first nominal is a KKT point of the nominal
+    NLP (independent certificate: CPU dynamics and Jacobians) and the script's closed loop (rti = 1, one fast-SLS step, N = 15, seed-0 noise) solves
     every MPC step.  IPOPT's own nominal is not available offline: parity unpinned for the trajectory values."""
     from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
     from problems import host_ddyn
@@ -520,7 +520,10 @@ def test_script_rocket_x0_runs_closed_loop_from_the_gpu_initialiser():
     cl = ClosedLoopMPC(m, N, B)
     cl.reset(x0, solve_nominal=True, continuation=2)
     X, U = cl.f.get("nominal_x", (N + 1, m.nx)), cl.f.get("nominal_u", (N, m.nu))
+    assert (cl.nlp_status == 0).all(), (cl.nlp_status, cl.nlp_info[:, :8])
     for b in range(B):
+        kdef, kviol, kstat, kpin, _ = _nlp_kkt_residual(m, N, X[b], U[b], x0[b])        # independent KKT certificate of the nominal NLP
+        assert kdef < 1e-6 and kviol < 1e-8 and kstat < 1e-5 and kpin < 1e-9, (kdef, kviol, kstat, kpin)
         assert np.abs(X[b, 0] - x0[b]).max() < 1e-9
         defect = max(np.abs(host_ddyn(m.model_id, X[b, k], U[b, k]) - X[b, k + 1]).max() for k in range(N))
         assert defect < 1e-6, defect

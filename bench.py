@@ -193,44 +193,54 @@ def main():
                                     "peak_TFLOPs": 78.6, "note": "vector fp64 peak = matrix fp64 peak on MI355X (BASELINE.md, AMD public figure)"},
                            "sweep_avg_launch_ms": sw_ms, "slice_gpu_ms_per_step": [round(a["total"] / args.steps, 2) for a in acc]}
         if n_sl > 1:
-            # the same kernel with the whole batch in ONE slice (no concurrent launches), two extra steps outside the timed region: with
-            # several slices the HIP-event duration of a launch includes the time it shares the GPU with the other slices' launches
-            pmc1 = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_single_slice.json")
-            one = SlicedDeviceBatch(make_solver, batch, 1)
-            one.run(1)
-            one.kernel_timing()
-            one.run(2)
-            ms1, n1, sw1, _ = one.kernel_timing()
-            one.close()
-            a1 = per_inst * float(sw1) / max(1, n1) / (ms1 / max(1, n1) * 1e-3) / 1e9
-            out["roofline"]["single_slice"] = {"achieved": a1, "frac": a1 / 8000.0, "avg_launch_ms": ms1 / max(1, n1), "launches": n1,
-                                               "algorithmic_bytes_per_launch": per_inst * float(sw1) / max(1, n1),
-                                               "traffic": json.load(open(pmc1)).get("k_ne_fwd_bytes_per_launch") if os.path.exists(pmc1) else None,
-                                               "note": "whole batch as one slice, 2 steps after the timed region (traffic: profiles/r01/pmc_traffic_single_slice.json)"}
+          try:
+              # the same kernel with the whole batch in ONE slice (no concurrent launches), two extra steps outside the timed region: with
+              # several slices the HIP-event duration of a launch includes the time it shares the GPU with the other slices' launches
+              pmc1 = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_single_slice.json")
+              one = SlicedDeviceBatch(make_solver, batch, 1)
+              one.run(1)
+              one.kernel_timing()
+              one.run(2)
+              ms1, n1, sw1, _ = one.kernel_timing()
+              one.close()
+              a1 = per_inst * float(sw1) / max(1, n1) / (ms1 / max(1, n1) * 1e-3) / 1e9
+              out["roofline"]["single_slice"] = {"achieved": a1, "frac": a1 / 8000.0, "avg_launch_ms": ms1 / max(1, n1), "launches": n1,
+                                                 "algorithmic_bytes_per_launch": per_inst * float(sw1) / max(1, n1),
+                                                 "traffic": json.load(open(pmc1)).get("k_ne_fwd_bytes_per_launch") if os.path.exists(pmc1) else None,
+                                                 "note": "whole batch as one slice, 2 steps after the timed region (traffic: profiles/r01/pmc_traffic_single_slice.json)"}
+          except Exception as e:      # never lose the headline line to an auxiliary measurement
+            out["roofline"]["single_slice"] = {"error": repr(e)}
         if getattr(m, "model_id", None) is not None:
-            # the step in front of the path (SCP_SLS.update_jacobian -> slsqp_linearize: RK4 + forward-mode AD Jacobians, c, g, q, bounds), timed on
-            # its own after the timed region: the synthetic instances above come with their A, B, so it is not part of `value`
-            import ctypes as C
-            from robust_nonlinear_mpc_amd import _lib as L
-            g0 = dict(np.load(fixture))
-            rng = np.random.default_rng(7)
-            lf = make_solver(B)
-            Xn = torch.from_numpy(np.tile(g0["X"], (B, 1, 1)) + 1e-3 * rng.standard_normal((B, N + 1, m.nx))).cuda()
-            Un = torch.from_numpy(np.tile(g0["U"], (B, 1, 1)) + 1e-3 * rng.standard_normal((B, N, m.nu))).cuda()
-            ptr = lambda t: C.c_void_p(t.data_ptr())
-            for _ in range(2):
-                L.check(lf.lib.slsqp_linearize(lf.h, ptr(Xn), ptr(Un), L.DEVICE))
-            torch.cuda.synchronize()
-            tl = time.perf_counter()
-            for _ in range(5):
-                L.check(lf.lib.slsqp_linearize(lf.h, ptr(Xn), ptr(Un), L.DEVICE))
-            torch.cuda.synchronize()
-            lin_ms = 1e3 * (time.perf_counter() - tl) / 5
-            lf.close()
-            out["config"]["linearise_ms_per_batch"] = lin_ms
-            out["config"]["ms_per_step_with_linearisation_upper_bound"] = out["ms_per_step"] + lin_ms
+          try:
+              # the step in front of the path (SCP_SLS.update_jacobian -> slsqp_linearize: RK4 + forward-mode AD Jacobians, c, g, q, bounds), timed on
+              # its own after the timed region: the synthetic instances above come with their A, B, so it is not part of `value`
+              import ctypes as C
+              from robust_nonlinear_mpc_amd import _lib as L
+              g0 = dict(np.load(fixture))
+              rng = np.random.default_rng(7)
+              lf = make_solver(B)
+              Xn = torch.from_numpy(np.tile(g0["X"], (B, 1, 1)) + 1e-3 * rng.standard_normal((B, N + 1, m.nx))).cuda()
+              Un = torch.from_numpy(np.tile(g0["U"], (B, 1, 1)) + 1e-3 * rng.standard_normal((B, N, m.nu))).cuda()
+              ptr = lambda t: C.c_void_p(t.data_ptr())
+              for _ in range(2):
+                  L.check(lf.lib.slsqp_linearize(lf.h, ptr(Xn), ptr(Un), L.DEVICE))
+              torch.cuda.synchronize()
+              tl = time.perf_counter()
+              for _ in range(5):
+                  L.check(lf.lib.slsqp_linearize(lf.h, ptr(Xn), ptr(Un), L.DEVICE))
+              torch.cuda.synchronize()
+              lin_ms = 1e3 * (time.perf_counter() - tl) / 5
+              lf.close()
+              out["config"]["linearise_ms_per_batch"] = lin_ms
+              out["config"]["ms_per_step_with_linearisation_upper_bound"] = out["ms_per_step"] + lin_ms
+          except Exception as e:
+            out["config"]["linearise_ms_per_batch"] = None
+            out["config"]["linearise_error"] = repr(e)
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(batch, min(B, 4096), budget_s=12.0)
+            try:
+                out["cpu_baseline"] = cpu_baseline(batch, min(B, 4096), budget_s=12.0)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -2,91 +2,239 @@
 """bench.py -- headline benchmark of the fast-SLS QP path (BASELINE.json: "QP solves/sec (whole node) + ms/MPC-step,
 rockETH N=20 batch=4096").
 
-A "step" is one MPC step of the hot path over one batch of synthetic instances resident in HBM:
-update_dynamics_list + update_linear_cost + fast_SLS.solve in the reference's closed-loop setting for the rocket
-(rti=1, fast_sls_rti_steps=1: 2 QP solves + 1 SLS sweep per instance, expe/main_rocket_robust_closed_loop.py:80-85).
-value = QP solves / s over all ranks (weak scaling: every rank owns its own 4096 instances; the only collective is one
-RCCL all-gather of the resulting first inputs / nominal trajectories at the end).
+A "step" is one closed-loop MPC step of the whole batch, entirely on the device (slsqp_cl_step):
+    warm-start shift + solver reset -> linearise (RK4 + forward-mode AD) -> fast-SLS RTI solve (QP #1, eta, SLS sweep, tightening,
+    QP #2; rti = 1, fast_sls_rti_steps = 1 as in expe/main_rocket_robust_closed_loop.py:80-85) -> nominal += delta -> plant + noise
+for 4096 rocket runs per GPU that differ in their disturbance seed (BASELINE config 5's shape: seed s reproduces the stream of
+np.random.seed(s), w_t = 2 rand(17) - 1), started from the script's initial state scaled to 0.3 of its distance from hover, nominal
+from the GPU initialiser (untimed set-up).  Warm-up steps are the first closed-loop steps, the timed steps the ones that follow.
+value = QP solves / s over all ranks (weak scaling: every rank owns its own 4096 seeds; the only collective is one RCCL all-gather
+of the measured states and applied inputs at the end of the timed region).
+
+`--workload synthetic` times round 1's step (seeded synthetic instances, update_dynamics + update_linear_cost + solve); the default
+run reports it as a labelled secondary figure.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 FIXTURE = {"rocket": "sweep_rocket_N20_s0.npz", "quadrotor": "sweep_quadrotor_N20_s0.npz", "pendulum": "sweep_pendulum_N10_s0.npz"}
 QP_BYTES = {"rocket": 93656, "quadrotor": 64504, "pendulum": 6112}     # algorithmic bytes per QP solve (SURVEY.md 8d)
+SWEEP_MFLOP = 9.0                                                      # per rocket N=20 instance (SURVEY.md 8d), scaled with nx^3 N^2 otherwise
+X0_SCALE = {"rocket": 0.3, "quadrotor": 1.0, "pendulum": 1.0}
 
 
-def cpu_baseline(batch, n_inst, budget_s=12.0):
-    """Reference-class CPU path (oracle: OSQP-class ADMM + polish with upstream default settings, numba-kernel restatement for
-    the sweep) on the first instances of the same workload: first one thread, then one instance per thread on all host cores
-    this process may use.  The oracle's C kernels are called through ctypes, which releases the GIL."""
-    import concurrent.futures as cf
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle import oracle as O
-    m, N = batch["model"], batch["N"]
-    d = O.dims_of(m.nx, m.nu, m.nw, N, m.ni, m.ni_f)
-
-    def one(b):
-        f = O.OracleFastSLS(d, m.G, m.Gf, m.g, m.gf, batch["E"], m.Q, m.R, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, O.default_settings())
-        f.set_rti_steps(1)
-        f.update_dynamics_list(batch["A"][b], batch["B"][b], batch["E"], list(batch["g"][b]) + [batch["gN"][b]], batch["c"][b])
-        f.update_linear_cost(batch["q"][b])
-        f.solve(batch["x0_arg"][b])
-        return 2
-
-    def run(threads, budget):
-        t0 = time.perf_counter()
-        done = 0
-        if threads == 1:
-            for b in range(n_inst):
-                one(b)
-                done += 1
-                if time.perf_counter() - t0 > budget:
-                    break
-        else:
-            with cf.ThreadPoolExecutor(threads) as ex:
-                chunk = 4 * threads
-                for lo in range(0, n_inst, chunk):
-                    done += len(list(ex.map(one, range(lo, min(n_inst, lo + chunk)))))
-                    if time.perf_counter() - t0 > budget:
-                        break
-        dt = time.perf_counter() - t0
-        return 2 * done / dt, done, dt
-
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
-    v1, n1, t1 = run(1, budget_s)
-    vc, nc, tc = (v1, n1, t1) if cores == 1 else run(cores, budget_s)
-    return {"value": vc, "unit": "QP solves/s", "cores": cores, "kind": "port", "single_thread_value": v1,
-            "sample": f"rocket-class instances x 1 RTI MPC step (2 QP + 1 sweep) each, OSQP-class restatement with upstream default settings + "
-                      f"polish: {nc} instances on {cores} threads in {tc:.1f} s; {n1} instances on 1 thread in {t1:.1f} s"}
-
-
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--model", default="rocket")
+    ap.add_argument("--workload", default="closed_loop", choices=["closed_loop", "synthetic"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (synthetic step, single-slice roofline block)")
     ap.add_argument("--slices", type=int, default=3, help="independent slices of the rank's batch, each with its own handle / HIP stream / host thread")
     ap.add_argument("--qp-eps", type=float, default=None, help="interior-point tolerance before the polish (default: the library's 1e-6)")
     ap.add_argument("--precision", type=int, default=0, help="0: fp64 (headline); 1: mixed fp32 factorisation / fp64 residuals (secondary figure)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU) as fresh children -- before this process
+    makes any GPU call -- and pass their single JSON line through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle; C threads)
+# --------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(m, N, data, budget_s=10.0):
+    """The oracle's RTI fast-SLS step (OSQP-class ADMM restatement with upstream default settings + polish, numba-kernel restatement for the
+    sweep) on the first instances of the SAME QPs the GPU solved in its last timed step, driven by C threads (oracle/sls_oracle.c
+    so_rti_step_batch: no interpreter lock): one thread, then one instance per thread on all host cores this process may use."""
+    from oracle import oracle as O
+    d = O.dims_of(m.nx, m.nu, m.nw, N, m.ni, m.ni_f)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    import numpy as np
+    E = np.stack([m.E] * (N + 1))
+    args = (d, data["A"], data["Bm"], data["g"], data["gN"], data["c"], data["q"], data["x0_arg"], m.G, m.Gf, m.gf, E, m.Q, m.R, m.Qf,
+            m.Q_reg, m.R_reg, m.Q_reg_f, O.default_settings())
+
+    def run(threads, budget):
+        t0 = time.perf_counter()
+        _, ok, done = O.rti_step_batch(*args, nthreads=threads, budget_s=budget)
+        dt = time.perf_counter() - t0
+        return 2 * done / dt, done, dt, float(ok[:done].mean()) if done else 0.0
+
+    v1, n1, t1, ok1 = run(1, 0.6 * budget_s)
+    vc, nc, tc, okc = (v1, n1, t1, ok1) if cores == 1 else run(cores, budget_s)
+    return {"value": vc, "unit": "QP solves/s", "cores": cores, "kind": "port", "single_thread_value": v1, "solved_frac": okc,
+            "sample": f"the QPs of the GPU's last timed step, first instances of rank 0, 1 RTI MPC step (2 QP + 1 sweep) each, OSQP-class restatement "
+                      f"with upstream default settings + polish, C threads: {nc} instances on {cores} threads in {tc:.1f} s; {n1} instances on 1 thread "
+                      f"in {t1:.1f} s"}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# closed-loop workload: K free-running slices of the rank's seeds
+# --------------------------------------------------------------------------------------------------------------------
+class ClosedLoopSlices:
+    def __init__(self, m, N, seeds, n_slices, steps_total, device, tune):
+        import numpy as np
+        import torch
+        from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream
+        self.m, self.N, self.torch = m, N, torch
+        B = len(seeds)
+        K = max(1, min(int(n_slices), B))
+        self.bounds = [(B * k // K, B * (k + 1) // K) for k in range(K)]
+        self.cl, self.W = [], []
+        dev = torch.device("cuda", device)
+        for lo, hi in self.bounds:
+            cl = ClosedLoopMPC(m, N, hi - lo, device=device)
+            tune(cl.f)
+            self.cl.append(cl)
+            W = np.stack([disturbance_stream(s, steps_total, m.nx) for s in seeds[lo:hi]], axis=1)      # (steps, b, nx)
+            self.W.append(torch.from_numpy(np.ascontiguousarray(W)).to(dev))
+        torch.cuda.synchronize()
+        self.step_no = 0
+        self.stats = [[] for _ in self.cl]       # per slice: list over steps of qp_stats (b,2,8)
+
+    def setup(self, x0):
+        import numpy as np
+        self._threads(lambda k: self.cl[k].reset(np.tile(x0, (self.cl[k].B, 1)), solve_nominal=True))
+        return np.concatenate([cl.nlp_status for cl in self.cl])
+
+    def _threads(self, fn):
+        err = []
+
+        def work(k):
+            try:
+                fn(k)
+            except Exception as e:      # surface worker failures in the caller
+                err.append(e)
+        if len(self.cl) == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(k,)) for k in range(len(self.cl))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if err:
+            raise err[0]
+
+    def run(self, steps, collect_stats=True):
+        """`steps` closed-loop MPC steps of every slice, each slice on its own thread / stream without waiting for the others.
+        Returns per-slice sums of the GPU times (ms) of the linearisations, QP solves and sweeps."""
+        import ctypes as C
+        import numpy as np
+        from robust_nonlinear_mpc_amd import _lib as L
+        acc = [dict(jac=0.0, qp=0.0, sweep=0.0, total=0.0) for _ in self.cl]
+        first = self.step_no
+
+        def work(k):
+            cl, W = self.cl[k], self.W[k]
+            f = cl.f
+            for i in range(first, first + steps):
+                L.check(f.lib.slsqp_cl_step(f.h, cl.rti, C.c_void_p(W[i].data_ptr()), L.DEVICE, C.byref(f.opts)))
+                t = f.timing_ms()
+                for key in acc[k]:
+                    acc[k][key] += t[key]
+                if collect_stats:
+                    self.stats[k].append(f.get("qp_stats", (2, 8), np.int32))
+        self._threads(work)
+        self.step_no += steps
+        return acc
+
+    def fetch_device(self, name, shape):
+        import ctypes as C
+        from robust_nonlinear_mpc_amd import _lib as L
+        outs = []
+        for cl in self.cl:
+            f = cl.f
+            out = self.torch.empty((f.B,) + tuple(shape), dtype=self.torch.float64, device=self.W[0].device)
+            L.check(f.lib.slsqp_get(f.h, name.encode(), C.c_void_p(out.data_ptr()), L.DEVICE))
+            outs.append(out)
+        return self.torch.cat(outs, dim=0)
+
+    def get(self, name, shape, dtype=None):
+        import numpy as np
+        return np.concatenate([cl.f.get(name, shape, dtype or np.float64) for cl in self.cl], axis=0)
+
+    def kernel_timing(self):
+        tot = [0.0, 0, 0, 0]
+        self.fwd_factor_sweeps = 0
+        for cl in self.cl:
+            ms, n = cl.f.kernel_timing()
+            tot[0] += ms; tot[1] += n; tot[2] += cl.f.fwd_instance_sweeps; tot[3] += cl.f.mx_retries
+            self.fwd_factor_sweeps += cl.f.fwd_factor_sweeps
+        return tuple(tot)
+
+    def close(self):
+        for cl in self.cl:
+            cl.close()
+
+
+def qp_statistics(stats):
+    """stats: list over steps of (B,2,8) int arrays -> the per-QP figures the bench line reports (slot 0 = QP #1, slot 1 = QP #2)."""
+    import numpy as np
+    out = {}
+    S = np.stack(stats)                                   # (steps, B, 2, 8)
+    for slot, name in ((0, "qp1"), (1, "qp2")):
+        q = S[:, :, slot, :]
+        its, blk, fac, nact, warm, rounds, st, fb = (q[..., i] for i in range(8))
+        solved = (st == 0) | (st == 4)
+        cold = its > 0
+        out[name] = {
+            "solved_frac": float(solved.mean()), "certified_frac": float((st == 0).mean()),
+            "started_warm_frac": float(warm.mean()), "cold_fallback_frac": float(fb.mean()), "interior_point_frac": float(cold.mean()),
+            "ipm_iters_mean": float(its[cold].mean()) if cold.any() else 0.0, "ipm_iters_p99": float(np.percentile(its[cold], 99)) if cold.any() else 0.0,
+            "ipm_iters_max": int(its.max()), "block_solves_mean": float(blk.mean()), "block_solves_p99": float(np.percentile(blk, 99)), "block_solves_max": int(blk.max()),
+            "factorisations_mean": float(fac.mean()),
+            "active_inequalities": {"mean": float(nact.mean()), "p50": float(np.percentile(nact, 50)), "p99": float(np.percentile(nact, 99)), "max": int(nact.max()),
+                                    "histogram_per_step": {"edges": [0, 1, 6, 11, 21, 41, 10 ** 9],
+                                                           "counts": [np.histogram(nact[s], bins=[0, 1, 6, 11, 21, 41, 10 ** 9])[0].tolist() for s in range(S.shape[0])]}},
+        }
+    return out
+
+
+def read_traffic(fname, key):
+    p = os.path.join(ROOT, "profiles", "r02", fname)
+    if not os.path.exists(p):
+        return None, None
+    d = json.load(open(p))
+    return d.get(key), f"profiles/r02/{fname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round, scripts/pmc_traffic.py; build {d.get('build', '?')})"
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or run `python bench.py --gpus N` "
+                         f"without a launcher\n")
+        sys.exit(2)
+
+    import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = local_rank % max(1, torch.cuda.device_count())
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
@@ -95,156 +243,186 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    from robust_nonlinear_mpc_amd import BatchedFastSLS, make_batch
+    from robust_nonlinear_mpc_amd import BatchedFastSLS, get_model, make_batch
     from robust_nonlinear_mpc_amd.fast_sls import SlicedDeviceBatch
     fixture = os.path.join(ROOT, "tests", "golden", FIXTURE[args.model])
     B = args.batch
-    batch = make_batch(args.model, fixture, B, seed=1234 + rank)
-    m, N = batch["model"], batch["N"]
+    m = get_model(args.model)
+    N = int(np.load(fixture)["N"])
+    nz = m.nx + m.nu
+    n_var = nz * N + m.nx
 
-    def make_solver(nb):
-        f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=nb, device=local_rank)
-        f.set_rti_steps(m.fast_sls_rti_steps if args.model == "rocket" else 1)
+    def tune(f, synthetic=False):
         f.opts.warm_rounds = int(os.environ.get('QP_WARM_ROUNDS', '4'))
         f.opts.precision = args.precision
+        f.opts.time_kernels = 1          # HIP events around every launch of the dominant kernel, on its own stream (roofline leg)
         if args.qp_eps is not None:
             f.opts.qp_eps = args.qp_eps
-        f.opts.warm_start = 0   # QP#1 of every step is solved cold (fresh Monte-Carlo instances); QP#2 warm-starts from QP#1
-        return f
-
-    # the rank's 4096 instances as `--slices` independent slices (own handle / HIP stream / host thread each): instances are
-    # independent, so one slice's few-instance solver tails overlap the other slices' bulk launches (fast_sls.SlicedDeviceBatch)
-    dev = SlicedDeviceBatch(make_solver, batch, args.slices)
-    f0 = dev.solvers[0]
-    n_var, n_con = f0.n, f0.mb + m.nx
+        if synthetic:
+            f.opts.warm_start = 0        # fresh instances every step: QP#1 solved cold; QP#2 warm-starts from QP#1
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def collect():
-        u0 = dev.fetch_device("primal_vec", (n_var,))[:, m.nx:m.nx + m.nu].contiguous()
+    def gather(t):
         if world > 1:
-            src = u0 if args.backend == "nccl" else u0.cpu()
-            gathered = [torch.empty_like(src) for _ in range(world)]
-            dist.all_gather(gathered, src)          # RCCL over xGMI: collect the first inputs of every instance
-            return gathered
-        return u0
+            src = t if args.backend == "nccl" else t.cpu()
+            out = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(out, src)                 # RCCL over xGMI: the only collective of the path
+            return out
+        return t
 
-    dev.run(args.warmup)
-    collect()   # warm the gather path too (first-use kernel loads are not part of the step)
-    barrier()
-    dev.kernel_timing()   # reset the per-kernel accumulators
-    t0 = time.perf_counter()
-    acc = dev.run(args.steps)
-    collect()
-    barrier()
-    dt = time.perf_counter() - t0
+    def make_synth(n_slices, seed):
+        batch = make_batch(args.model, fixture, B, seed=seed)
+
+        def make_solver(nb):
+            f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=nb, device=local_rank)
+            f.set_rti_steps(m.fast_sls_rti_steps if args.model == "rocket" else 1)
+            tune(f, synthetic=True)
+            return f
+        return SlicedDeviceBatch(make_solver, batch, n_slices), batch
+
+    per_inst = 8 * (N * m.nx * nz + 2 * n_var + N * m.nx)      # algorithmic bytes of one instance forward sweep: A_k, B_k in, rhs slices in, u out
+
+    def roof_block(fwd_ms_total, launches, inst_sweeps):
+        fwd_ms = fwd_ms_total / max(1, launches)
+        alg = per_inst * float(inst_sweeps) / max(1, launches)
+        ach = alg / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
+        return {"achieved": ach, "frac": ach / 8000.0, "avg_launch_ms": fwd_ms, "launches": launches, "algorithmic_bytes_per_launch": alg}
+
+    out = {}
+    if args.workload == "closed_loop":
+        seeds = rank * B + np.arange(B)
+        x0 = m.x_ref + X0_SCALE[args.model] * (m.extra["x0"] - m.x_ref) if "x0" in m.extra else m.x_ref + 0.02 * (m.x_ub - m.x_lb)
+        dev = ClosedLoopSlices(m, N, seeds, args.slices, args.warmup + args.steps, local_rank, tune)
+        nlp = dev.setup(x0)
+        dev.run(args.warmup, collect_stats=False)
+        gather(torch.cat([dev.fetch_device("x_meas", (m.nx,)), dev.fetch_device("u0", (m.nu,))], dim=1))     # warm the gather path
+        barrier()
+        dev.kernel_timing()
+        t0 = time.perf_counter()
+        acc = dev.run(args.steps)
+        gather(torch.cat([dev.fetch_device("x_meas", (m.nx,)), dev.fetch_device("u0", (m.nu,))], dim=1))
+        barrier()
+        dt = time.perf_counter() - t0
+        workload = (f"{args.model} N={N} batch={B}/GPU closed-loop Monte-Carlo, one slsqp_cl_step per step (shift + reset, linearise, fast-SLS RTI: 2 QP solves + 1 SLS "
+                    f"sweep per instance, nominal update, plant + seeded noise); x0 = hover + {X0_SCALE[args.model]} (script x0 - hover), nominal from the GPU "
+                    f"initialiser (untimed); timed steps = closed-loop steps {args.warmup}..{args.warmup + args.steps - 1}")
+        qstat = qp_statistics([np.concatenate([dev.stats[k][s] for k in range(len(dev.cl))]) for s in range(args.steps)])
+        succ = dev.get("scp_success", (), np.int32)
+        extra_cfg = {"nominal_initialiser_converged_frac": float((nlp == 0).mean()), "mpc_step_success_frac_last_step": float(succ.mean()), "qp": qstat,
+                     "linearise_ms_per_step": float(np.mean([a["jac"] for a in acc])) / args.steps}
+    else:
+        dev, batch = make_synth(args.slices, 1234 + rank)
+        dev.run(args.warmup)
+        gather(dev.fetch_device("primal_vec", (n_var,))[:, m.nx:m.nx + m.nu].contiguous())
+        barrier()
+        dev.kernel_timing()
+        t0 = time.perf_counter()
+        acc = dev.run(args.steps)
+        gather(dev.fetch_device("primal_vec", (n_var,))[:, m.nx:m.nx + m.nu].contiguous())
+        barrier()
+        dt = time.perf_counter() - t0
+        workload = (f"{args.model} N={N} batch={B}/GPU synthetic instances (seeded perturbations of one nominal; 0-8 active inequalities), fast-SLS RTI step "
+                    f"(update_dynamics + update_linear_cost + solve: 2 QP solves + 1 SLS sweep per instance), no linearisation")
+        extra_cfg = {}
     fwd_total_ms, fwd_launches, inst_sweeps, mx_retries = dev.kernel_timing()
     fact_sweeps = dev.fwd_factor_sweeps
     if world > 1:
         tmax = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    st = dev.get("status", (), np.int32)
-    its = dev.get("qp_iters", (), np.int32)
-    qps_per_step = 2 * B            # RTI: QP#1 + QP#2 per instance
-    n_sl = len(dev.slices)
-    value = qps_per_step * world * args.steps / dt
+    n_sl = len(dev.bounds)
+    value = 2 * B * world * args.steps / dt
+    headline = (args.model, B, args.workload) == ("rocket", 4096, "closed_loop")
     out = {
-        "metric": ("QP solves/sec (whole node), rockETH N=20 batch=4096 RTI MPC step" if (args.model, B) == ("rocket", 4096)
-                   else f"QP solves/sec (whole node), {args.model} N={N} batch={B} RTI MPC step"), "value": value, "unit": "QP solves/s",
+        "metric": ("QP solves/sec (whole node), rockETH N=20 batch=4096 closed-loop RTI MPC step" if headline
+                   else f"QP solves/sec (whole node), {args.model} N={N} batch={B} {args.workload} RTI MPC step"), "value": value, "unit": "QP solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 0 else "f32 factorisation + f64 residuals (mixed)", "data": "synthetic",
-        "config": {"workload": f"{args.model} N={N} batch={B}/GPU, fast-SLS RTI step (rti_steps=1: 2 QP solves + 1 SLS sweep per instance)",
-                   "qp_n": n_var, "qp_m": n_con, "slices_per_gpu": n_sl, "solved_frac": float(np.mean((st == 0) | (st == 4))),
-                   "polished_frac": float(np.mean(st == 0)), "ipm_iters_mean_last_qp": float(its.mean()), "ipm_iters_max_last_qp": int(its.max()),
-                   "qp2_cold_fallback_frac": float(np.mean(its > 0)), "tightened_frac": float(np.mean(dev.get("backoff_x", (N + 1, m.nx)).max(axis=(1, 2)) > 0))},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 0 else "f32 factorisation + f64 residuals (mixed)",
+        "data": "synthetic",
+        "config": dict({"workload": workload, "qp_n": n_var, "qp_m": N * (m.nx + m.ni) + m.ni_f + m.nx, "slices_per_gpu": n_sl}, **extra_cfg),
     }
     if rank == 0:
-        kk = dev.get("kkt", (8,))
-        # dominant kernel: k_ne_fwd (block-tridiagonal forward sweep; re-factorises in half of its launches).  Algorithmic bytes of one
-        # instance sweep: A_k,B_k of all stages in, rhs slices (Pi, v) in, u out; a launch moves that for every instance it works on
-        # (device counter of instance sweeps / launches); time = HIP events around every launch on the launching stream.
-        nz = m.nx + m.nu
-        per_inst = 8 * (N * m.nx * nz + 2 * n_var + N * m.nx)
-        fwd_ms = fwd_total_ms / max(1, fwd_launches)
-        alg_bytes_launch = per_inst * float(inst_sweeps) / max(1, fwd_launches)
-        achieved = alg_bytes_launch / (fwd_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("k_ne_fwd_bytes_per_launch")
-        solves = 2 * args.steps * n_sl                          # QP solve calls in the timed region (each over one slice)
-        qp_ms = sum(a["qp"] for a in acc) / solves
-        sw_ms = sum(a["sweep"] for a in acc) / (args.steps * n_sl)
-        out["roofline"] = {"bound": "hbm", "kernel": "k_ne_fwd", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                           "traffic": traffic, "avg_launch_ms": fwd_ms, "launches": fwd_launches, "algorithmic_bytes_per_launch": alg_bytes_launch,
-                           "qp_solve": {"avg_ms": qp_ms, "instances": B / n_sl, "algorithmic_bytes": QP_BYTES[args.model] * B / n_sl,
-                                        "achieved_GBps": QP_BYTES[args.model] * B / n_sl / (qp_ms * 1e-3) / 1e9,
-                                        "note": "one solve call = one slice; slices run concurrently, so these times overlap"},
-                           "last_qp_block_solves_per_instance": {"factorising": float(kk[:, 6].mean()), "all": float(kk[:, 7].mean())},
-                           # second ceiling: fp64 work of the timed region / wall time against the vector = matrix fp64 peak.  Per instance
-                           # sweep of N stages: 28.6 kflop per factorising stage, 2 kflop per forward / backward substitution stage;
-                           # SLS sweep 9.0 Mflop per rocket instance (scaled with nx^3 for the other plants)
-                           "fp64": {"achieved_TFLOPs": (fact_sweeps * N * 28.6e3 * (m.nx / 17.0) ** 3 + (2 * inst_sweeps - fact_sweeps) * N * 2.0e3 * (m.nx / 17.0) ** 2
-                                                        + args.steps * B * 9.0e6 * (m.nx / 17.0) ** 3 * (N / 20.0) ** 2) / dt / 1e12,
-                                    "peak_TFLOPs": 78.6, "note": "vector fp64 peak = matrix fp64 peak on MI355X (BASELINE.md, AMD public figure)"},
-                           "sweep_avg_launch_ms": sw_ms, "slice_gpu_ms_per_step": [round(a["total"] / args.steps, 2) for a in acc]}
-        if n_sl > 1:
-          try:
-              # the same kernel with the whole batch in ONE slice (no concurrent launches), two extra steps outside the timed region: with
-              # several slices the HIP-event duration of a launch includes the time it shares the GPU with the other slices' launches
-              pmc1 = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_single_slice.json")
-              one = SlicedDeviceBatch(make_solver, batch, 1)
-              one.run(1)
-              one.kernel_timing()
-              one.run(2)
-              ms1, n1, sw1, _ = one.kernel_timing()
-              one.close()
-              a1 = per_inst * float(sw1) / max(1, n1) / (ms1 / max(1, n1) * 1e-3) / 1e9
-              out["roofline"]["single_slice"] = {"achieved": a1, "frac": a1 / 8000.0, "avg_launch_ms": ms1 / max(1, n1), "launches": n1,
-                                                 "algorithmic_bytes_per_launch": per_inst * float(sw1) / max(1, n1),
-                                                 "traffic": json.load(open(pmc1)).get("k_ne_fwd_bytes_per_launch") if os.path.exists(pmc1) else None,
-                                                 "note": "whole batch as one slice, 2 steps after the timed region (traffic: profiles/r01/pmc_traffic_single_slice.json)"}
-          except Exception as e:      # never lose the headline line to an auxiliary measurement
-            out["roofline"]["single_slice"] = {"error": repr(e)}
-        if getattr(m, "model_id", None) is not None:
-          try:
-              # the step in front of the path (SCP_SLS.update_jacobian -> slsqp_linearize: RK4 + forward-mode AD Jacobians, c, g, q, bounds), timed on
-              # its own after the timed region: the synthetic instances above come with their A, B, so it is not part of `value`
-              import ctypes as C
-              from robust_nonlinear_mpc_amd import _lib as L
-              g0 = dict(np.load(fixture))
-              rng = np.random.default_rng(7)
-              lf = make_solver(B)
-              Xn = torch.from_numpy(np.tile(g0["X"], (B, 1, 1)) + 1e-3 * rng.standard_normal((B, N + 1, m.nx))).cuda()
-              Un = torch.from_numpy(np.tile(g0["U"], (B, 1, 1)) + 1e-3 * rng.standard_normal((B, N, m.nu))).cuda()
-              ptr = lambda t: C.c_void_p(t.data_ptr())
-              for _ in range(2):
-                  L.check(lf.lib.slsqp_linearize(lf.h, ptr(Xn), ptr(Un), L.DEVICE))
-              torch.cuda.synchronize()
-              tl = time.perf_counter()
-              for _ in range(5):
-                  L.check(lf.lib.slsqp_linearize(lf.h, ptr(Xn), ptr(Un), L.DEVICE))
-              torch.cuda.synchronize()
-              lin_ms = 1e3 * (time.perf_counter() - tl) / 5
-              lf.close()
-              out["config"]["linearise_ms_per_batch"] = lin_ms
-              out["config"]["ms_per_step_with_linearisation_upper_bound"] = out["ms_per_step"] + lin_ms
-          except Exception as e:
-            out["config"]["linearise_ms_per_batch"] = None
-            out["config"]["linearise_error"] = repr(e)
-        if not args.no_cpu and world == 1:
+        st = dev.get("status", (), np.int32)
+        out["config"]["last_qp_solved_frac"] = float(np.mean((st == 0) | (st == 4)))
+        out["config"]["last_qp_certified_frac"] = float(np.mean(st == 0))
+        # dominant kernel: k_ne_fwd (block-tridiagonal forward sweep; re-factorises in about half of its launches).  A launch moves the algorithmic
+        # bytes of every instance it works on (device counter of instance sweeps / launches); time = HIP events around every launch on the launching stream.
+        rb = roof_block(fwd_total_ms, fwd_launches, inst_sweeps)
+        traffic, tsrc = read_traffic("pmc_traffic.json", "k_ne_fwd_bytes_per_launch")
+        calls = args.steps * n_sl
+        sweep_flop = SWEEP_MFLOP * 1e6 * (m.nx / 17.0) ** 3 * (N / 20.0) ** 2
+        fp64 = (fact_sweeps * N * 28.6e3 * (m.nx / 17.0) ** 3 + (2 * inst_sweeps - fact_sweeps) * N * 2.0e3 * (m.nx / 17.0) ** 2 + args.steps * B * sweep_flop) / dt / 1e12
+        out["roofline"] = dict({"bound": "hbm", "kernel": "k_ne_fwd", "peak": 8000.0, "unit": "GB/s", "traffic": traffic, "traffic_source": tsrc}, **rb)
+        out["roofline"].update({
+            "qp_solve": {"avg_ms": sum(a["qp"] for a in acc) / (2 * calls), "instances": B / n_sl, "algorithmic_bytes": QP_BYTES[args.model] * B / n_sl,
+                         "note": "one solve call = one slice; slices run concurrently, so these times overlap"},
+            # second ceiling: fp64 work of the timed region / wall time against the vector = matrix fp64 peak.  Per instance sweep of N stages:
+            # 28.6 kflop per factorising stage, 2 kflop per forward / backward substitution stage; SLS sweep 9.0 Mflop per rocket instance
+            "fp64": {"achieved_TFLOPs": fp64, "peak_TFLOPs": 78.6, "frac": fp64 / 78.6, "note": "vector fp64 peak = matrix fp64 peak on MI355X (BASELINE.md, AMD public figure)"},
+            "sweep_avg_launch_ms": sum(a["sweep"] for a in acc) / calls, "slice_gpu_ms_per_step": [round(a["total"] / args.steps, 2) for a in acc]})
+        cpu_data = None
+        if args.workload == "closed_loop" and not args.no_cpu and world == 1:
+            f0 = dev.cl[0].f
+            ncpu = min(f0.B, 1024)
+            cpu_data = {k: f0.get(k, shp)[:ncpu] for k, shp in (("A", (N, m.nx, m.nx)), ("Bm", (N, m.nx, m.nu)), ("c", (N, m.nx)), ("g", (N, m.ni)), ("gN", (m.ni_f,)),
+                                                                 ("q", (n_var,)), ("x0_arg", (m.nx,)))}
+        elif args.workload == "synthetic" and not args.no_cpu and world == 1:
+            ncpu = min(B, 1024)
+            cpu_data = {"A": batch["A"][:ncpu], "Bm": batch["B"][:ncpu], "c": batch["c"][:ncpu], "g": batch["g"][:ncpu], "gN": batch["gN"][:ncpu], "q": batch["q"][:ncpu],
+                        "x0_arg": batch["x0_arg"][:ncpu]}
+        dev.close()
+        if not args.no_secondary and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(batch, min(B, 4096), budget_s=12.0)
+                # the same kernels with the whole batch in ONE slice (no concurrent launches) after the timed region: with several slices the HIP-event
+                # duration of a launch includes the time it shares the GPU with the other slices' launches
+                if n_sl > 1 and args.workload == "closed_loop":
+                    one = ClosedLoopSlices(m, N, seeds, 1, args.warmup + args.steps, local_rank, tune)
+                    one.setup(x0)
+                    one.run(args.warmup, collect_stats=False)
+                    torch.cuda.synchronize()
+                    one.kernel_timing()
+                    t1 = time.perf_counter()
+                    a1 = one.run(args.steps, collect_stats=False)
+                    torch.cuda.synchronize()
+                    dt1 = time.perf_counter() - t1
+                    ms1, n1, sw1, _ = one.kernel_timing()
+                    one.close()
+                    tr1, ts1 = read_traffic("pmc_traffic_single_slice.json", "k_ne_fwd_bytes_per_launch")
+                    out["roofline"]["single_slice"] = dict(roof_block(ms1, n1, sw1), traffic=tr1, traffic_source=ts1, ms_per_step=1e3 * dt1 / args.steps,
+                                                           gpu_ms_per_step={k: a1[0][k] / args.steps for k in a1[0]},
+                                                           note="same closed-loop steps with the whole batch as one slice, after the timed region")
+            except Exception as e:      # never lose the headline line to an auxiliary measurement
+                out["roofline"]["single_slice"] = {"error": repr(e)}
+            try:
+                if args.workload == "closed_loop":
+                    syn, _ = make_synth(args.slices, 1234)
+                    syn.run(1)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    syn.run(3)
+                    torch.cuda.synchronize()
+                    dts = (time.perf_counter() - t1) / 3
+                    sst = syn.get("status", (), np.int32)
+                    syn.close()
+                    out["secondary"] = {"workload": "round-1 headline: synthetic instances (0-8 active inequalities of 874), update_dynamics + update_linear_cost + solve, "
+                                                    "no linearisation, QP#1 cold every step", "ms_per_step": 1e3 * dts, "qp_solves_per_s": 2 * B / dts,
+                                        "certified_frac": float(np.mean(sst == 0)), "steps": 3, "slices": args.slices}
+            except Exception as e:
+                out["secondary"] = {"error": repr(e)}
+        if cpu_data is not None:
+            try:
+                out["cpu_baseline"] = cpu_baseline(m, N, cpu_data)
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    dev.close()
+    else:
+        dev.close()
     if world > 1:
         dist.destroy_process_group()
 

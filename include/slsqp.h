@@ -70,6 +70,8 @@ typedef struct {
     int precision;       /* 0 (default): fp64 throughout.  1: mixed -- block factorisations, stored inverses and substitutions in fp32,
                             right-hand sides / residuals / KKT certificate in fp64, two more refinement solves per polish; instances
                             that do not certify are solved again in fp64 (BASELINE config 3, "fp32 vs fp64") */
+    int time_kernels;    /* 0 (default): no per-launch timing.  1: HIP event pairs around every launch of the dominant QP kernel on the
+                            handle's stream, read with slsqp_kernel_timing (bench.py's roofline leg) */
 } slsqp_opts;
 
 void slsqp_default_opts(slsqp_opts *o);
@@ -127,13 +129,14 @@ int slsqp_linearize(slsqp_handle *h, const double *X, const double *U, int loc);
    converge mode (rti = -1, SCP_SLS_jit.py:20-21,113-135): iterate every instance until |delta_vec|inf < opts.scp_eps, at most
    opts.max_scp_iter times; an instance whose fast-SLS step fails leaves the loop (:118-119).  w (B,nx) disturbance sample or NULL.
    Results via slsqp_get: nominal_x (N+1,nx) nominal_u (N,nu) x_meas (nx) u0 (nu) scp_success[int32] (1) scp_iterations[int32] (1)
-   scp_delta_max (1) + all names of the fast-SLS result (for each instance: of its last fast-SLS solve). */
+   scp_delta_max (1) primal_infeasibility (1; max_k,i (ddyn(x_k,u_k) - x_{k+1})_i of the updated nominal, SCP_SLS_jit.py:449-456) + all names of the fast-SLS result (for each instance: of its last fast-SLS solve). */
 int slsqp_cl_init(slsqp_handle *h, const double *x_meas, const double *X_nom, const double *U_nom, const double *u_init, int loc);
 int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc, const slsqp_opts *opts);
 /* Device-side log of the closed loop: every following slsqp_cl_step stores what the scripts keep per MPC step
    (expe/main_rocket_robust_closed_loop.py:160-178) in entry `step` of (B, max_steps, ...) device buffers, so a Monte-Carlo run makes no
    host round trip per step.  slsqp_get names (per instance): log_state (S,nx) log_u0 (S,nu) log_nominal_x (S,N+1,nx) log_nominal_u (S,N,nu)
-   log_backoff_x (S,N+1,nx) log_backoff_u (S,N,nu) log_success[int32] (S) log_scp_iterations[int32] (S).  slsqp_cl_init restarts at entry 0. */
+   log_backoff_x (S,N+1,nx) log_backoff_u (S,N,nu) log_success[int32] (S) log_scp_iterations[int32] (S) log_primal_infeasibility (S).
+   slsqp_cl_init restarts at entry 0. */
 int slsqp_cl_log(slsqp_handle *h, int max_steps);
 
 /* ---- nominal-trajectory initialiser: replaces the reference's IPOPT call for the first MPC step
@@ -162,13 +165,14 @@ int slsqp_qp_solve(slsqp_handle *h, double *x, double *y, int *status, int *iter
 int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta_f, double *K, double *beta, double *beta_f,
                 double *backoff, double *backoff_f, int loc);
 
-/* elapsed GPU time (ms) of the kernels launched by the last slsqp_solve / slsqp_qp_solve / slsqp_sweep call,
-   measured with HIP events on the handle's stream: [0] total, [1] QP kernel(s), [2] sweep kernel, [3] other */
-int slsqp_last_timing(slsqp_handle *h, double *ms4);
+/* elapsed GPU time (ms) of the kernels launched by the last slsqp_solve / slsqp_qp_solve / slsqp_sweep / slsqp_cl_step call,
+   measured with HIP events on the handle's stream: [0] total, [1] QP kernel(s), [2] sweep kernel, [3] other,
+   [4] linearisation of the last slsqp_cl_step (the reference's t_jac, SCP_SLS_jit.py:268,339-341).  ms5 must hold 5 doubles. */
+int slsqp_last_timing(slsqp_handle *h, double *ms5);
 /* accumulated since the last call: [0] total ms of k_ne_fwd launches (HIP events around each launch, handle's stream),
    [1] number of launches, [2] instances re-solved in fp64 after a mixed-precision attempt, [3] instance-sweeps those launches did,
    [4] how many of them factorised (device counters); resets the accumulators.  out must hold 5 doubles. */
-int slsqp_kernel_timing(slsqp_handle *h, double *out4);
+int slsqp_kernel_timing(slsqp_handle *h, double *out5);
 void *slsqp_stream(slsqp_handle *h); /* hipStream_t, for callers that share device buffers */
 
 #ifdef __cplusplus

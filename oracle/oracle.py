@@ -373,3 +373,22 @@ class OracleFastSLS:
         out["cost_tube"] = np.nan
         out["cost"] = np.nan
         return out
+
+
+def rti_step_batch(d, A, B, g, gN, c, q, x0, G, Gf, gf_raw, E, Q, R, Qf, Q_reg, R_reg, Q_reg_f, settings=None, nthreads=1, budget_s=0.0):
+    """One RTI fast-SLS step (rti_steps = 1: QP, eta, sweep, tightened QP) for a batch of fresh instances, driven by C threads
+    (so_rti_step_batch): the CPU baseline of bench.py without the interpreter lock.  Arrays carry a leading batch axis.
+    Returns (primal (nb,n), ok (nb) int32, done): instances are processed in order until all are done or budget_s seconds have passed."""
+    s = settings or default_settings()
+    A, B, g, gN, c, q, x0 = map(_c, (A, B, g, gN, c, q, x0))
+    G, Gf, gf_raw, E, Q, R, Qf, Q_reg, R_reg, Q_reg_f = map(_c, (G, Gf, gf_raw, E, Q, R, Qf, Q_reg, R_reg, Q_reg_f))
+    nb = A.shape[0]
+    n = (d.nx + d.nu) * d.N + d.nx
+    primal = np.zeros((nb, n))
+    ok = np.zeros(nb, dtype=np.int32)
+    f = lib().so_rti_step_batch
+    f.restype = C.c_int
+    done = f(C.byref(d), C.c_int(nb), C.c_int(int(nthreads)), C.c_double(float(budget_s)), _p(A), _p(B), _p(g), _p(gN), _p(c), _p(q), _p(x0),
+             _p(G), _p(Gf), _p(gf_raw), _p(E), _p(Q), _p(R), _p(Qf), _p(Q_reg), _p(R_reg), _p(Q_reg_f), C.byref(s), _p(primal),
+             ok.ctypes.data_as(C.c_void_p))
+    return primal, ok, int(done)

@@ -685,3 +685,98 @@ void so_qp_kkt(const so_dims *d, const double *A, const double *B, const double 
     out[0] = st; out[1] = pv; out[2] = ds; out[3] = cp;
     free(t1); free(t2); free(z); qp_free(&q);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch driver for the CPU baseline of bench.py: one RTI fast-SLS step (fast_SLS.solve with rti_steps = 1,
+ * solver/fast_SLS_jit.py:278-327: QP #1, evaluate_dual_eta, Riccati sweep, propagate, back-off, tightened QP #2)
+ * for nb independent instances on nthreads POSIX threads, one instance per thread at a time -- the same
+ * sequence oracle.py's OracleFastSLS.solve drives from Python, restated here so the all-core figure is not
+ * limited by the interpreter lock.  Bounds as update_dynamics + offset_constraints (qp_jit.py:268-273, 595-610)
+ * and update_tightening (fast_SLS_jit.py:556-569) set them, quirks q2/q3 included.
+ * Inputs per instance b: A (N,nx,nx) B (N,nx,nu) g (N,ni) gN (ni_f) c (N,nx) q (n) x0 (nx); shared: G, Gf, gf_raw, E (N+1,nx,nw), weights.
+ * Outputs: primal (nb,n) of the last QP, ok (nb): 1 = both QPs solved.
+ * ---------------------------------------------------------------------------------------------- */
+#include <pthread.h>
+typedef struct {
+    const so_dims *d; int nb; const double *A, *B, *g, *gN, *c, *q, *x0, *G, *Gf, *gf_raw, *E, *Q, *R, *Qf, *Qreg, *Rreg, *Qregf;
+    const so_osqp_settings *st; double *primal; int *ok; int *next; pthread_mutex_t *mu; double budget_s, t0; int *done;
+} rti_job;
+
+static double wall_s(void) { return now_ms() * 1e-3; }
+
+static void rti_one(const rti_job *J, int b) {
+    const so_dims *d = J->d;
+    const int nx = d->nx, nu = d->nu, nw = d->nw, N = d->N, ni = d->ni, nif = d->ni_f, nz = nx + nu, SR = nx + ni;
+    const int n = nz * N + nx, mb = N * SR + nif, m = mb + nx;
+    const double EPS = 1e-10, BIG = 1e20;
+    const double *A = J->A + (size_t)b * N * nx * nx, *B = J->B + (size_t)b * N * nx * nu, *g = J->g + (size_t)b * N * ni,
+                 *gN = J->gN + (size_t)b * nif, *c = J->c + (size_t)b * N * nx, *q = J->q + (size_t)b * n, *x0 = J->x0 + (size_t)b * nx;
+    double *l = (double *)malloc(sizeof(double) * m), *u = (double *)malloc(sizeof(double) * m), *x = (double *)calloc(n, sizeof(double)),
+           *y = (double *)calloc(m, sizeof(double));
+    for (int k = 0; k < N; k++) {
+        for (int i = 0; i < nx; i++) { u[k * SR + i] = -c[k * nx + i] + EPS; l[k * SR + i] = -c[k * nx + i] - EPS; }
+        for (int i = 0; i < ni; i++) { u[k * SR + nx + i] = g[k * ni + i] + EPS; l[k * SR + nx + i] = -BIG; }
+    }
+    for (int i = 0; i < nif; i++) { u[N * SR + i] = gN[i] + EPS; l[N * SR + i] = -BIG; }
+    for (int i = 0; i < nx; i++) { u[mb + i] = -x0[i] + EPS; l[mb + i] = -x0[i] - EPS; }
+    so_osqp_info info;
+    int ok = 0;
+    so_qp_solve(d, A, B, J->G, J->Gf, J->Q, J->R, J->Qf, q, l, u, J->st, x, y, &info);
+    if (info.status == 1 || info.status == 2) {
+        double *eta = (double *)calloc((size_t)N * N * ni, sizeof(double)), *eta_f = (double *)calloc((size_t)(N + 1) * nif, sizeof(double));
+        const double s0 = 2.0 * sqrt(EPS);                                  /* beta = eps everywhere after initialize_backoff */
+        for (int kk = 0; kk < N; kk++) for (int jj = 0; jj <= kk; jj++) for (int i = 0; i < ni; i++) eta[((size_t)kk * N + jj) * ni + i] = y[kk * SR + nx + i] / s0;
+        for (int jj = 0; jj <= N; jj++) for (int i = 0; i < nif; i++) eta_f[(size_t)jj * nif + i] = y[N * SR + i] / s0;
+        double *S = (double *)malloc(sizeof(double) * (size_t)(N + 1) * (N + 1) * nx * nx), *K = (double *)calloc((size_t)N * (N + 1) * nu * nx, sizeof(double));
+        double *Px = (double *)malloc(sizeof(double) * (size_t)(N + 1) * (N + 1) * nx * nw), *Pu = (double *)malloc(sizeof(double) * (size_t)N * (N + 1) * nu * nw);
+        double *beta = (double *)malloc(sizeof(double) * (size_t)N * N * ni), *beta_f = (double *)malloc(sizeof(double) * (size_t)(N + 1) * nif);
+        double *bo = (double *)malloc(sizeof(double) * (size_t)N * ni), *bof = (double *)malloc(sizeof(double) * nif);
+        memset(S, 0, sizeof(double) * (size_t)(N + 1) * (N + 1) * nx * nx);
+        so_backward(d, A, B, J->G, J->Gf, eta, eta_f, J->Qreg, J->Rreg, J->Qregf, S, K);
+        so_propagate(d, A, B, J->E, K, Px, Pu);
+        so_backoff(d, Px, Pu, J->G, J->Gf, EPS, beta, beta_f, bo, bof);
+        for (int k = 0; k < N; k++) {
+            for (int i = 0; i < nx; i++) u[k * SR + i] = -c[k * nx + i];                        /* no +eps (quirk q3) */
+            for (int i = 0; i < ni; i++) u[k * SR + nx + i] = g[k * ni + i] - bo[k * ni + i];
+        }
+        for (int i = 0; i < nif; i++) u[N * SR + i] = J->gf_raw[i] - bof[i];                    /* raw gf (quirk q2) */
+        so_qp_solve(d, A, B, J->G, J->Gf, J->Q, J->R, J->Qf, q, l, u, J->st, x, y, &info);
+        ok = (info.status == 1 || info.status == 2);
+        free(eta); free(eta_f); free(S); free(K); free(Px); free(Pu); free(beta); free(beta_f); free(bo); free(bof);
+    }
+    memcpy(J->primal + (size_t)b * n, x, sizeof(double) * n);
+    J->ok[b] = ok;
+    free(l); free(u); free(x); free(y);
+}
+
+static void *rti_worker(void *arg) {
+    rti_job *J = (rti_job *)arg;
+    for (;;) {
+        pthread_mutex_lock(J->mu);
+        int b = *J->next;
+        const int stop = b >= J->nb || (J->budget_s > 0 && wall_s() - J->t0 > J->budget_s);
+        if (!stop) *J->next = b + 1;
+        pthread_mutex_unlock(J->mu);
+        if (stop) return NULL;
+        rti_one(J, b);
+        pthread_mutex_lock(J->mu); *J->done += 1; pthread_mutex_unlock(J->mu);
+    }
+}
+
+/* Returns the number of instances completed (instances are taken in order until nb are done or budget_s seconds have passed). */
+int so_rti_step_batch(const so_dims *d, int nb, int nthreads, double budget_s, const double *A, const double *B, const double *g, const double *gN,
+                      const double *c, const double *q, const double *x0, const double *G, const double *Gf, const double *gf_raw, const double *E,
+                      const double *Q, const double *R, const double *Qf, const double *Qreg, const double *Rreg, const double *Qregf,
+                      const so_osqp_settings *st, double *primal, int *ok) {
+    pthread_mutex_t mu;
+    pthread_mutex_init(&mu, NULL);
+    int next = 0, done = 0;
+    rti_job J = {d, nb, A, B, g, gN, c, q, x0, G, Gf, gf_raw, E, Q, R, Qf, Qreg, Rreg, Qregf, st, primal, ok, &next, &mu, budget_s, wall_s(), &done};
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, rti_worker, &J);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(th);
+    pthread_mutex_destroy(&mu);
+    return done;
+}

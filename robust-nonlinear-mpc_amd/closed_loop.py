@@ -78,8 +78,8 @@ class ClosedLoopMPC:
             nominal_x=f.get("nominal_x", (N + 1, m.nx)), nominal_u=f.get("nominal_u", (N, m.nu)),
             backoff_x=f.get("backoff_x", (N + 1, m.nx)), backoff_u=f.get("backoff_u", (N, m.nu)),
             success=f.get("scp_success", (), np.int32).astype(bool), status=f.get("status", (), np.int32),
-            scp_iterations=f.get("scp_iterations", (), np.int32),
-            t_qp_ms=f.timing_ms()["qp"], t_riccati_ms=f.timing_ms()["sweep"],
+            scp_iterations=f.get("scp_iterations", (), np.int32), primal_infeasibility=f.get("primal_infeasibility", ()),
+            t_qp_ms=f.timing_ms()["qp"], t_riccati_ms=f.timing_ms()["sweep"], t_jac_ms=f.timing_ms()["jac"],
         )
 
     def run_on_device(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False, continuation=1):
@@ -88,11 +88,11 @@ class ClosedLoopMPC:
         f, m, N, B = self.f, self.m, self.N, self.B
         L.check(f.lib.slsqp_cl_log(f.h, int(steps)))
         self.reset(x0, X_nom, U_nom, solve_nominal=solve_nominal, continuation=continuation)
-        t_qp, t_ric = np.zeros((steps, 1)), np.zeros((steps, 1))
+        t_qp, t_ric, t_jac = np.zeros((steps, 1)), np.zeros((steps, 1)), np.zeros((steps, 1))
         for i in range(steps):
             self.step(None if W is None else W[i], fetch=False)
             t = f.timing_ms()
-            t_qp[i], t_ric[i] = t["qp"], t["sweep"]
+            t_qp[i], t_ric[i], t_jac[i] = t["qp"], t["sweep"], t["jac"]
         lx = f.get("log_nominal_x", (steps, N + 1, m.nx)); lu = f.get("log_nominal_u", (steps, N, m.nu))
         lbx = f.get("log_backoff_x", (steps, N + 1, m.nx)); lbu = f.get("log_backoff_u", (steps, N, m.nu))
         u0 = f.get("log_u0", (steps, m.nu))
@@ -101,8 +101,9 @@ class ClosedLoopMPC:
             input_trajectory=u0[:, :max(steps - 1, 0)].transpose(0, 2, 1).copy(),
             nominal_trajectory_x=lx.transpose(0, 3, 2, 1).copy(), nominal_trajectory_u=lu.transpose(0, 3, 2, 1).copy(),
             backoff_trajectory_x=lbx.transpose(0, 3, 2, 1).copy(), backoff_trajectory_u=lbu.transpose(0, 3, 2, 1).copy(),
-            t_jac=np.full((steps, 1), np.nan), t_qp=t_qp, t_riccati=t_ric,
+            t_jac=t_jac, t_qp=t_qp, t_riccati=t_ric,
             success=f.get("log_success", (steps,), np.int32).astype(bool), scp_iterations=f.get("log_scp_iterations", (steps,), np.int32),
+            primal_infeasibility=f.get("log_primal_infeasibility", (steps,)),
         )
 
     def run(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False):
@@ -114,8 +115,9 @@ class ClosedLoopMPC:
             state_trajectory=np.zeros((B, m.nx, steps)), input_trajectory=np.zeros((B, m.nu, max(steps - 1, 0))),
             nominal_trajectory_x=np.zeros((B, m.nx, N + 1, steps)), nominal_trajectory_u=np.zeros((B, m.nu, N, steps)),
             backoff_trajectory_x=np.zeros((B, m.nx, N + 1, steps)), backoff_trajectory_u=np.zeros((B, m.nu, N, steps)),
-            t_jac=np.full((steps, 1), np.nan), t_qp=np.zeros((steps, 1)), t_riccati=np.zeros((steps, 1)),
+            t_jac=np.zeros((steps, 1)), t_qp=np.zeros((steps, 1)), t_riccati=np.zeros((steps, 1)),
             success=np.zeros((B, steps), dtype=bool), scp_iterations=np.zeros((B, steps), dtype=np.int32),
+            primal_infeasibility=np.full((B, steps), np.nan),
         )
         for i in range(steps):
             r = self.step(None if W is None else W[i])
@@ -126,7 +128,8 @@ class ClosedLoopMPC:
             out["nominal_trajectory_u"][:, :, :, i] = r["nominal_u"].transpose(0, 2, 1)
             out["backoff_trajectory_x"][:, :, :, i] = r["backoff_x"].transpose(0, 2, 1)
             out["backoff_trajectory_u"][:, :, :, i] = r["backoff_u"].transpose(0, 2, 1)
-            out["t_qp"][i], out["t_riccati"][i] = r["t_qp_ms"], r["t_riccati_ms"]
+            out["t_qp"][i], out["t_riccati"][i], out["t_jac"][i] = r["t_qp_ms"], r["t_riccati_ms"], r["t_jac_ms"]
+            out["primal_infeasibility"][:, i] = r["primal_infeasibility"]
             out["success"][:, i] = r["success"]
             out["scp_iterations"][:, i] = r["scp_iterations"]
         return out

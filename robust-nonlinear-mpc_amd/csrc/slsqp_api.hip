@@ -31,7 +31,7 @@ extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
     o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-6; o->conv_tol = 1e-3;
     o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 4;
-    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0;
+    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0;
 }
 
 struct slsqp_handle {
@@ -47,23 +47,27 @@ struct slsqp_handle {
     double *primal, *dual, *cost, *pin_dual, *kkt, *prev_primal, *Linv, *ws, *qpstate;
     double *eta, *eta_f, *beta, *beta_f, *backoff, *backoff_f, *backoff_x, *backoff_u, *K;
     int *status, *iters, *itnum, *has_prev, *conv, *alive, *mask, *success, *infeas, *counter;
-    int *scp_active, *scp_success, *scp_iters, *pending_reset; double *scp_dmax;
+    int *scp_active, *scp_success, *scp_iters, *pending_reset, *scp_upd; double *scp_dmax;
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
     int *retry; int mx_retry, mx_retry_total;
+    int *qpstat;                // (B,2,8) per-QP statistics, see QpArgs::qpstat
+    int *stale;                 // (B) bit 0: eta / eta_f, bit 1: K hold values from before the last slsqp_reset (zeroed lazily on slsqp_get)
+    double *pinf; double t_jac;  // primal_infeasibility of the last SCP update (SCP_SLS_jit.py:449-456); linearisation time of the last cl_step
     // qp-level CSC maps
     int *mapA, *mapB;  // CSC offsets of A_k[i][j] / B_k[i][j]
     double *stage;     // staging buffer for host<->device transfers
     size_t stage_bytes;
     bool have_costs, have_cons, have_dyn;
     hipEvent_t ev[8];
-    std::vector<hipEvent_t> kev;   // event pairs around every k_ne_fwd launch of the last QP solve
-    int n_kev;
+    std::vector<hipEvent_t> kev;   // event pairs around every k_ne_fwd launch of the last QP solve (only with opts.time_kernels)
+    int n_kev; bool time_kernels;
     double t_total, t_qp, t_sweep, t_fwd; int n_fwd; double fwd_inst;   // fwd_inst: sum over launches of instances that did work
     std::map<std::string, std::pair<void *, size_t>> named;  // name -> (device ptr, bytes per instance)
     unsigned long long *inst_launches;                       // device counter: instance-sweeps done by k_ne_fwd (roofline accounting)
     double *ct_part, *cost_tube;                             // sweep's per-column parts of cost_tube^2 and the result
+    std::vector<void *> owned, log_owned;                    // device buffers of the handle / of its closed-loop log
     int log_steps;                                           // device-side closed-loop log (slsqp_cl_log): capacity in MPC steps, 0 = off
-    double *lg_x, *lg_u, *lg_bx, *lg_bu, *lg_state, *lg_u0; int *lg_succ, *lg_it;
+    double *lg_x, *lg_u, *lg_bx, *lg_bu, *lg_state, *lg_u0, *lg_pinf; int *lg_succ, *lg_it;
 };
 
 static Costs costs_of(slsqp_handle *h) {
@@ -74,11 +78,14 @@ static Costs costs_of(slsqp_handle *h) {
 }
 
 template <typename T>
-static int dalloc(T **p, size_t count) {
+static int dalloc(std::vector<void *> &owned, T **p, size_t count) {
+    *p = nullptr;
     HIPCHK(hipMalloc((void **)p, count * sizeof(T) + 64));
+    owned.push_back((void *)*p);
     HIPCHK(hipMemset(*p, 0, count * sizeof(T)));
     return 0;
 }
+static void free_all(std::vector<void *> &owned) { for (void *p : owned) if (p) hipFree(p); owned.clear(); }
 
 static bool supported_dims(int nx, int nu) { return (nx == 4 && nu == 1) || (nx == 13 && nu == 4) || (nx == 17 && nu == 4); }
 
@@ -106,29 +113,30 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     const size_t B = batch;
     if (hipStreamCreate(&h->st) != hipSuccess) { fail("hipStreamCreate"); delete h; return nullptr; }
     int rc = 0;
-    rc |= dalloc(&h->A, B * N * nx * nx); rc |= dalloc(&h->Bm, B * N * nx * nu); rc |= dalloc(&h->E, (size_t)(N + 1) * nx * nw);
-    rc |= dalloc(&h->g, B * N * ni); rc |= dalloc(&h->gN, B * nif); rc |= dalloc(&h->c, B * N * nx); rc |= dalloc(&h->q, B * h->n);
-    rc |= dalloc(&h->x0val, B * nx); rc |= dalloc(&h->gf_raw, (size_t)nif); rc |= dalloc(&h->g_raw, (size_t)ni);
-    rc |= dalloc(&h->Xn, B * (N + 1) * nx); rc |= dalloc(&h->Un, B * N * nu); rc |= dalloc(&h->xmeas, B * nx); rc |= dalloc(&h->x0arg, B * nx);
-    rc |= dalloc(&h->u0, B * nu); rc |= dalloc(&h->wbuf, B * nx); rc |= dalloc(&h->u_init, (size_t)nu); h->cl_steps = 0; rc |= dalloc(&h->cst, (size_t)(3 * nx + 2 * nu) * 2);
-    rc |= dalloc(&h->ubg, B * h->mb); rc |= dalloc(&h->lbg, B * h->mb);
-    rc |= dalloc(&h->primal, B * h->n); rc |= dalloc(&h->dual, B * h->mb); rc |= dalloc(&h->cost, B); rc |= dalloc(&h->pin_dual, B * nx);
-    rc |= dalloc(&h->kkt, B * 8); rc |= dalloc(&h->prev_primal, B * h->n); rc |= dalloc(&h->Linv, B * N * nx * nx); rc |= dalloc(&h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(&h->qpstate, B * 20);
-    rc |= dalloc(&h->eta, B * N * N * ni); rc |= dalloc(&h->eta_f, B * (N + 1) * nif); rc |= dalloc(&h->beta, B * N * N * ni);
-    rc |= dalloc(&h->beta_f, B * (N + 1) * nif); rc |= dalloc(&h->backoff, B * N * ni); rc |= dalloc(&h->backoff_f, B * nif);
-    rc |= dalloc(&h->backoff_x, B * (N + 1) * nx); rc |= dalloc(&h->backoff_u, B * N * nu); rc |= dalloc(&h->K, B * N * (N + 1) * nu * nx);
-    rc |= dalloc(&h->status, B); rc |= dalloc(&h->iters, B); rc |= dalloc(&h->itnum, B); rc |= dalloc(&h->has_prev, B); rc |= dalloc(&h->conv, B);
-    rc |= dalloc(&h->alive, B); rc |= dalloc(&h->mask, B); rc |= dalloc(&h->success, B); rc |= dalloc(&h->infeas, B); rc |= dalloc(&h->counter, (size_t)4);
-    rc |= dalloc(&h->scp_active, B); rc |= dalloc(&h->scp_success, B); rc |= dalloc(&h->scp_iters, B); rc |= dalloc(&h->pending_reset, B); rc |= dalloc(&h->scp_dmax, B);
-    rc |= dalloc(&h->retry, B); h->mx_retry = 0; h->mx_retry_total = 0;
-    rc |= dalloc(&h->nom_st, B * 12); rc |= dalloc(&h->nom_need_lin, B); rc |= dalloc(&h->nom_status, B); rc |= dalloc(&h->nom_iters, B);
-    rc |= dalloc(&h->mapA, (size_t)N * nx * nx); rc |= dalloc(&h->mapB, (size_t)N * nx * nu);
-    rc |= dalloc(&h->inst_launches, (size_t)2); rc |= dalloc(&h->ct_part, B * (N + 1)); rc |= dalloc(&h->cost_tube, B);
-    h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = nullptr; h->lg_succ = h->lg_it = nullptr;
-    if (rc) { delete h; return nullptr; }
+    rc |= dalloc(h->owned, &h->A, B * N * nx * nx); rc |= dalloc(h->owned, &h->Bm, B * N * nx * nu); rc |= dalloc(h->owned, &h->E, (size_t)(N + 1) * nx * nw);
+    rc |= dalloc(h->owned, &h->g, B * N * ni); rc |= dalloc(h->owned, &h->gN, B * nif); rc |= dalloc(h->owned, &h->c, B * N * nx); rc |= dalloc(h->owned, &h->q, B * h->n);
+    rc |= dalloc(h->owned, &h->x0val, B * nx); rc |= dalloc(h->owned, &h->gf_raw, (size_t)nif); rc |= dalloc(h->owned, &h->g_raw, (size_t)ni);
+    rc |= dalloc(h->owned, &h->Xn, B * (N + 1) * nx); rc |= dalloc(h->owned, &h->Un, B * N * nu); rc |= dalloc(h->owned, &h->xmeas, B * nx); rc |= dalloc(h->owned, &h->x0arg, B * nx);
+    rc |= dalloc(h->owned, &h->u0, B * nu); rc |= dalloc(h->owned, &h->wbuf, B * nx); rc |= dalloc(h->owned, &h->u_init, (size_t)nu); h->cl_steps = 0; rc |= dalloc(h->owned, &h->cst, (size_t)(3 * nx + 2 * nu) * 2);
+    rc |= dalloc(h->owned, &h->ubg, B * h->mb); rc |= dalloc(h->owned, &h->lbg, B * h->mb);
+    rc |= dalloc(h->owned, &h->primal, B * h->n); rc |= dalloc(h->owned, &h->dual, B * h->mb); rc |= dalloc(h->owned, &h->cost, B); rc |= dalloc(h->owned, &h->pin_dual, B * nx);
+    rc |= dalloc(h->owned, &h->kkt, B * 8); rc |= dalloc(h->owned, &h->prev_primal, B * h->n); rc |= dalloc(h->owned, &h->Linv, B * N * nx * nx); rc |= dalloc(h->owned, &h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(h->owned, &h->qpstate, B * 20);
+    rc |= dalloc(h->owned, &h->eta, B * N * N * ni); rc |= dalloc(h->owned, &h->eta_f, B * (N + 1) * nif); rc |= dalloc(h->owned, &h->beta, B * N * N * ni);
+    rc |= dalloc(h->owned, &h->beta_f, B * (N + 1) * nif); rc |= dalloc(h->owned, &h->backoff, B * N * ni); rc |= dalloc(h->owned, &h->backoff_f, B * nif);
+    rc |= dalloc(h->owned, &h->backoff_x, B * (N + 1) * nx); rc |= dalloc(h->owned, &h->backoff_u, B * N * nu); rc |= dalloc(h->owned, &h->K, B * N * (N + 1) * nu * nx);
+    rc |= dalloc(h->owned, &h->status, B); rc |= dalloc(h->owned, &h->iters, B); rc |= dalloc(h->owned, &h->itnum, B); rc |= dalloc(h->owned, &h->has_prev, B); rc |= dalloc(h->owned, &h->conv, B);
+    rc |= dalloc(h->owned, &h->alive, B); rc |= dalloc(h->owned, &h->mask, B); rc |= dalloc(h->owned, &h->success, B); rc |= dalloc(h->owned, &h->infeas, B); rc |= dalloc(h->owned, &h->counter, (size_t)4);
+    rc |= dalloc(h->owned, &h->scp_active, B); rc |= dalloc(h->owned, &h->scp_success, B); rc |= dalloc(h->owned, &h->scp_iters, B); rc |= dalloc(h->owned, &h->pending_reset, B); rc |= dalloc(h->owned, &h->scp_dmax, B);
+    rc |= dalloc(h->owned, &h->retry, B); h->mx_retry = 0; h->mx_retry_total = 0;
+    rc |= dalloc(h->owned, &h->nom_st, B * 12); rc |= dalloc(h->owned, &h->nom_need_lin, B); rc |= dalloc(h->owned, &h->nom_status, B); rc |= dalloc(h->owned, &h->nom_iters, B);
+    rc |= dalloc(h->owned, &h->mapA, (size_t)N * nx * nx); rc |= dalloc(h->owned, &h->mapB, (size_t)N * nx * nu);
+    rc |= dalloc(h->owned, &h->inst_launches, (size_t)2); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
+    rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
+    h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr;
+    if (rc) { free_all(h->owned); hipStreamDestroy(h->st); delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
     h->kev.resize(2 * 256); for (auto &e : h->kev) hipEventCreate(&e);
-    h->n_kev = 0; h->t_fwd = 0; h->n_fwd = 0; h->fwd_inst = 0;
+    h->n_kev = 0; h->t_fwd = 0; h->n_fwd = 0; h->fwd_inst = 0; h->time_kernels = false;
     // CSC offsets of the reference's frozen pattern (qp_jit.py:101-123,178-186; columns sorted by row)
     {
         std::vector<int> mA((size_t)N * nx * nx), mB((size_t)N * nx * nu);
@@ -146,8 +154,9 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
                     p += nx; p += 2;
                 }
         }
-        hipMemcpy(h->mapA, mA.data(), mA.size() * sizeof(int), hipMemcpyHostToDevice);
-        hipMemcpy(h->mapB, mB.data(), mB.size() * sizeof(int), hipMemcpyHostToDevice);
+        hipMemcpyAsync(h->mapA, mA.data(), mA.size() * sizeof(int), hipMemcpyHostToDevice, h->st);
+        hipMemcpyAsync(h->mapB, mB.data(), mB.size() * sizeof(int), hipMemcpyHostToDevice, h->st);
+        hipStreamSynchronize(h->st);
     }
     h->stage = nullptr; h->stage_bytes = 0;
     h->have_costs = h->have_cons = h->have_dyn = false; h->model_id = -1;
@@ -167,6 +176,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     reg("nominal_x", h->Xn, sizeof(double) * (N + 1) * nx); reg("nominal_u", h->Un, sizeof(double) * N * nu); reg("x_meas", h->xmeas, sizeof(double) * nx); reg("u0", h->u0, sizeof(double) * nu);
     reg("A", h->A, sizeof(double) * N * nx * nx); reg("Bm", h->Bm, sizeof(double) * N * nx * nu); reg("c", h->c, sizeof(double) * N * nx);
     reg("g", h->g, sizeof(double) * N * ni); reg("gN", h->gN, sizeof(double) * nif); reg("q", h->q, sizeof(double) * h->n); reg("pin_dual", h->pin_dual, sizeof(double) * nx);
+    reg("primal_infeasibility", h->pinf, sizeof(double)); reg("qp_stats", h->qpstat, sizeof(int) * 16); reg("x0_arg", h->x0arg, sizeof(double) * nx);
     return h;
 }
 
@@ -174,14 +184,9 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     if (!h) return;
     hipSetDevice(h->dev);
     hipStreamSynchronize(h->st);
-    hipFree(h->inst_launches); hipFree(h->ct_part); hipFree(h->cost_tube);
-    { void *lg[] = {h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_succ, h->lg_it}; for (void *p : lg) if (p) hipFree(p); }
-    void *ptrs[] = {h->A, h->Bm, h->E, h->g, h->gN, h->c, h->q, h->x0val, h->gf_raw, h->g_raw, h->Xn, h->Un, h->xmeas, h->x0arg, h->u0, h->wbuf, h->u_init, h->cst, h->ubg, h->lbg, h->primal, h->dual, h->cost,
-                    h->pin_dual, h->kkt, h->prev_primal, h->Linv, h->ws, h->qpstate, h->eta, h->eta_f, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x,
-                    h->backoff_u, h->K, h->status, h->iters, h->itnum, h->has_prev, h->conv, h->alive, h->mask, h->success, h->infeas,
-                    h->counter, h->mapA, h->mapB, h->scp_active, h->scp_success, h->scp_iters, h->pending_reset, h->scp_dmax,
-                    h->nom_st, h->nom_need_lin, h->nom_status, h->nom_iters, h->retry};
-    for (void *p : ptrs) if (p) hipFree(p);
+    free_all(h->log_owned);
+    free_all(h->owned);
+    if (h->stage) hipFree(h->stage);
     for (auto &e : h->ev) hipEventDestroy(e);
     for (auto &e : h->kev) hipEventDestroy(e);
     hipStreamDestroy(h->st);
@@ -196,6 +201,18 @@ static int put(slsqp_handle *h, void *dst, const void *src, size_t bytes, int lo
     HIPCHK(hipMemcpyAsync(dst, src, bytes, loc == SLSQP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->st));
     if (loc == SLSQP_HOST) HIPCHK(hipStreamSynchronize(h->st));  // caller's buffer may be reused on return
     return 0;
+}
+
+// Device staging area for host-buffer (SLSQP_HOST) entry points: grown on demand, reused, filled with async copies on the handle's stream --
+// no hipMalloc / null-stream hipMemcpy per call (those serialise against every other handle's stream).
+static double *stage_buf(slsqp_handle *h, size_t bytes) {
+    if (bytes > h->stage_bytes) {
+        hipStreamSynchronize(h->st);
+        if (h->stage) { hipFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+        if (hipMalloc((void **)&h->stage, bytes + 64) != hipSuccess) { h->stage = nullptr; fail("hipMalloc (staging buffer)"); return nullptr; }
+        h->stage_bytes = bytes;
+    }
+    return h->stage;
 }
 
 static bool is_diag(const double *M, int n) {
@@ -267,7 +284,7 @@ __global__ void k_post_qp(int B, const int *status, int *alive, int *infeas) {
     if (b < B && alive[b]) { const int ok = (status[b] == 0 || status[b] == 4); if (!ok) { alive[b] = 0; infeas[b] = 1; } }
 }
 // after the convergence test: mask = instances that go on to Riccati + tightening (_step :318-326)
-__global__ void k_post_conv(int B, int rti, const int *conv, int *alive, int *mask, int *success, int *itnum, int *counter) {
+__global__ void k_post_conv(int B, int rti, const int *conv, int *alive, int *mask, int *success, int *itnum, int *counter, int *stale) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     int m = 0;
@@ -276,7 +293,7 @@ __global__ void k_post_conv(int B, int rti, const int *conv, int *alive, int *ma
         else m = 1;
     }
     mask[b] = m;
-    if (m) { itnum[b] += 1; atomicAdd(counter, 1); }
+    if (m) { itnum[b] += 1; stale[b] &= ~2; atomicAdd(counter, 1); }   // the sweep that follows rewrites this instance's K
 }
 __global__ void k_finish(int B, int rti, const int *alive, const int *infeas, int *success, const int *active, int *pending_reset) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,6 +312,16 @@ __global__ void k_apply_pending_reset(int B, int *pending, const int *active, in
     for (size_t o = threadIdx.x; o < netaf; o += blockDim.x) eta_f[(size_t)b * netaf + o] = 0.0;
     __syncthreads();
     if (threadIdx.x == 0) { itnum[b] = 0; pending[b] = 0; }
+}
+__global__ void k_and_int(int *p, int v, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] &= v; }
+// instances whose `bit` is set in stale[]: zero their slice of arr1 (and arr2), then clear the bit (last use decides: clear_bit)
+__global__ void k_zero_stale(int *stale, int bit, double *arr1, size_t n1, double *arr2, size_t n2) {
+    const int b = blockIdx.x;
+    if (!(stale[b] & bit)) return;
+    for (size_t o = threadIdx.x; o < n1; o += blockDim.x) arr1[(size_t)b * n1 + o] = 0.0;
+    if (arr2) for (size_t o = threadIdx.x; o < n2; o += blockDim.x) arr2[(size_t)b * n2 + o] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) stale[b] &= ~bit;
 }
 __global__ void k_copy_int(const int *src, int *dst, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[i]; }
 __global__ void k_split_lu(int B, int mb, int nx, const double *l, const double *u, double *lbg, double *ubg, double *x0val) {
@@ -334,7 +361,7 @@ static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter, bool mx) 
     while (tick < max_ticks && active > 0) {
         const int burst = tick < first_burst ? first_burst : tail_burst;
         for (int i = 0; i < burst; i++, tick++) {
-            const bool timed = h->n_kev + 2 <= (int)h->kev.size();
+            const bool timed = h->time_kernels && h->n_kev + 2 <= (int)h->kev.size();
             if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
             if (mx) hipLaunchKernelGGL((k_ne_fwd_mx<NX, NU>), grid, blk, lds, h->st, a);
             else hipLaunchKernelGGL((k_ne_fwd<NX, NU>), grid, blk, lds, h->st, a);
@@ -360,8 +387,9 @@ __global__ void k_mark_retry(int B, const int *run, const int *status, int *retr
     if (r) atomicAdd(count, 1);
 }
 
-static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr) {
+static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr, int stat_slot = 0) {
     QpArgs a;
+    a.qpstat = h->qpstat; a.stat_slot = stat_slot;
     a.prox = prox; a.prox_stride = 12; a.inst_launches = h->inst_launches;
     a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;
     a.cst = costs_of(h); a.Linv = h->Linv; a.ws = h->ws; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
@@ -369,6 +397,7 @@ static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int w
     a.state = h->qpstate; a.n_active = h->counter + 1; a.warm = warm; a.warm_rounds = o->warm_rounds;
     a.init_s = getenv("SLSQP_INIT_S") ? atof(getenv("SLSQP_INIT_S")) : 1.0; a.init_lam = getenv("SLSQP_INIT_LAM") ? atof(getenv("SLSQP_INIT_LAM")) : 0.0;
     const bool mx = o->precision == 1;
+    h->time_kernels = o->time_kernels != 0;
     a.n_refine = mx ? 3 : 1;   // fp64: one refinement solve; its forward sweep measures the dynamics residual of the first solve (certificate)
     if (getenv("SLSQP_NREFINE")) a.n_refine = atoi(getenv("SLSQP_NREFINE"));
     a.early_ctol = mx ? 1e-2 : 1e-6;
@@ -425,7 +454,8 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     if (loc == SLSQP_HOST) {
         std::vector<double> neg((size_t)B * d.nx);
         for (size_t i = 0; i < neg.size(); i++) neg[i] = -x0[i];
-        HIPCHK(hipMemcpy(h->x0val, neg.data(), neg.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(h->x0val, neg.data(), neg.size() * sizeof(double), hipMemcpyHostToDevice, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
     } else {
         hipLaunchKernelGGL(k_negate, dim3((B * d.nx + 255) / 256), dim3(256), 0, h->st, x0, h->x0val, B * d.nx);
     }
@@ -449,12 +479,12 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         if (launch_qp(h, h->alive, &o, (i > 0 || o.warm_start) ? 1 : 0)) return -1;
         HIPCHK(hipEventRecord(h->ev[2], h->st));
         hipLaunchKernelGGL(k_post_qp, dim3(gb), dim3(256), 0, h->st, B, h->status, h->alive, h->infeas);
-        EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff};
+        EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff, h->stale};
         hipLaunchKernelGGL(k_eta, dim3(B), dim3(256), 0, h->st, ea);
         ConvArgs ca{B, h->n, h->primal, h->prev_primal, h->has_prev, h->alive, h->conv, o.conv_tol};
         hipLaunchKernelGGL(k_conv, dim3(B), dim3(64), 0, h->st, ca);
         HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), h->st));
-        hipLaunchKernelGGL(k_post_conv, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->conv, h->alive, h->mask, h->success, h->itnum, h->counter);
+        hipLaunchKernelGGL(k_post_conv, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->conv, h->alive, h->mask, h->success, h->itnum, h->counter, h->stale);
         HIPCHK(hipEventRecord(h->ev[3], h->st));
         if (launch_sweep(h, h->mask, h->eta, h->eta_f, o.eps_backoff)) return -1;
         HIPCHK(hipEventRecord(h->ev[4], h->st));
@@ -468,7 +498,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     }
     // final QP: RTI always (fast_SLS_jit.py:293); converge mode only for instances that hit MAX_ITER (:311)
     HIPCHK(hipEventRecord(h->ev[1], h->st));
-    if (launch_qp(h, h->alive, &o, 1)) return -1;
+    if (launch_qp(h, h->alive, &o, 1, nullptr, 1)) return -1;
     HIPCHK(hipEventRecord(h->ev[2], h->st));
     hipLaunchKernelGGL(k_finish, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->alive, h->infeas, h->success, active, h->pending_reset);
     HIPCHK(hipEventRecord(h->ev[5], h->st));
@@ -480,15 +510,16 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
 
 extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts) { return solve_impl(h, x0, loc, opts, nullptr); }
 
-extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms4) {
-    ms4[0] = h->t_total; ms4[1] = h->t_qp; ms4[2] = h->t_sweep; ms4[3] = h->t_total - h->t_qp - h->t_sweep;
+extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms5) {
+    ms5[0] = h->t_total; ms5[1] = h->t_qp; ms5[2] = h->t_sweep; ms5[3] = h->t_total - h->t_qp - h->t_sweep; ms5[4] = h->t_jac;
     return 0;
 }
 extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out3) {
     unsigned long long il[2] = {0, 0};
     hipSetDevice(h->dev);
-    hipMemcpy(il, h->inst_launches, sizeof(il), hipMemcpyDeviceToHost);
-    hipMemset(h->inst_launches, 0, sizeof(il));
+    hipMemcpyAsync(il, h->inst_launches, sizeof(il), hipMemcpyDeviceToHost, h->st);
+    hipMemsetAsync(h->inst_launches, 0, sizeof(il), h->st);
+    hipStreamSynchronize(h->st);
     out3[0] = h->t_fwd; out3[1] = (double)h->n_fwd; out3[2] = (double)h->mx_retry_total; out3[3] = (double)il[0]; out3[4] = (double)il[1];
     h->t_fwd = 0; h->n_fwd = 0; h->mx_retry_total = 0;
     return 0;
@@ -499,6 +530,13 @@ extern "C" int slsqp_get(slsqp_handle *h, const char *name, void *out, int loc) 
     auto it = h->named.find(name);
     if (it == h->named.end()) return fail(std::string("unknown result name: ") + name);
     const size_t bytes = it->second.second * (size_t)h->B;
+    {   // arrays that slsqp_reset only marked stale
+        const slsqp_dims &d = h->d;
+        if (!strcmp(name, "eta") || !strcmp(name, "eta_f"))
+            hipLaunchKernelGGL(k_zero_stale, dim3(h->B), dim3(256), 0, h->st, h->stale, 1, h->eta, (size_t)d.N * d.N * d.ni, h->eta_f, (size_t)(d.N + 1) * d.ni_f);
+        else if (!strcmp(name, "K"))
+            hipLaunchKernelGGL(k_zero_stale, dim3(h->B), dim3(256), 0, h->st, h->stale, 2, h->K, (size_t)d.N * (d.N + 1) * d.nu * d.nx, (double *)nullptr, (size_t)0);
+    }
     HIPCHK(hipMemcpyAsync(out, it->second.first, bytes, loc == SLSQP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->st));
     HIPCHK(hipStreamSynchronize(h->st));
     return 0;
@@ -525,13 +563,13 @@ extern "C" int slsqp_reset(slsqp_handle *h) {
     // `_prev_primal_vec` is NOT cleared by the reference (quirk q5) and is not cleared here.
     const slsqp_dims &d = h->d;
     const size_t B = h->B;
-    HIPCHK(hipMemsetAsync(h->eta, 0, sizeof(double) * B * d.N * d.N * d.ni, h->st));
-    HIPCHK(hipMemsetAsync(h->eta_f, 0, sizeof(double) * B * (d.N + 1) * d.ni_f, h->st));
+    // eta, eta_f and K (1.5 GB at rocket B = 4096) are not cleared here: every entry the device reads is rewritten first (k_eta before the
+    // sweep, the sweep before anything reads K), so they are only marked stale and zeroed on demand when slsqp_get asks for them
+    hipLaunchKernelGGL(k_fill_int, dim3((h->B + 255) / 256), dim3(256), 0, h->st, h->stale, 3, h->B);
     HIPCHK(hipMemsetAsync(h->itnum, 0, sizeof(int) * B, h->st));
     HIPCHK(hipMemsetAsync(h->pending_reset, 0, sizeof(int) * B, h->st));
     HIPCHK(hipMemsetAsync(h->q, 0, sizeof(double) * B * h->n, h->st));
-    HIPCHK(hipMemsetAsync(h->K, 0, sizeof(double) * B * d.N * (d.N + 1) * d.nu * d.nx, h->st));
-    HIPCHK(hipStreamSynchronize(h->st));
+    (void)d;
     h->have_dyn = false;
     return 0;
 }
@@ -558,12 +596,12 @@ static int linearize_impl(slsqp_handle *h, const double *X, const double *U, int
     const slsqp_dims &d = h->d;
     const size_t B = h->B;
     const double *dX = X, *dU = U;
-    double *tmp = nullptr;
     if (loc == SLSQP_HOST) {
         const size_t nX = B * (d.N + 1) * d.nx, nU = B * d.N * d.nu;
-        HIPCHK(hipMalloc((void **)&tmp, sizeof(double) * (nX + nU)));
-        HIPCHK(hipMemcpy(tmp, X, sizeof(double) * nX, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(tmp + nX, U, sizeof(double) * nU, hipMemcpyHostToDevice));
+        double *tmp = stage_buf(h, sizeof(double) * (nX + nU));
+        if (!tmp) return -1;
+        HIPCHK(hipMemcpyAsync(tmp, X, sizeof(double) * nX, hipMemcpyHostToDevice, h->st));
+        HIPCHK(hipMemcpyAsync(tmp + nX, U, sizeof(double) * nU, hipMemcpyHostToDevice, h->st));
         dX = tmp; dU = tmp + nX;
     }
     LinArgs a{h->B, d.N, dX, dU, h->g_raw, h->gf_raw, costs_of(h), h->A, h->Bm, h->c, h->g, h->gN, h->q, run};
@@ -574,8 +612,7 @@ static int linearize_impl(slsqp_handle *h, const double *X, const double *U, int
     BoundsArgs ba{h->B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->ubg, h->lbg, 1e-10, run};
     hipLaunchKernelGGL(k_set_bounds, dim3(1024), dim3(256), 0, h->st, ba);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->st));
-    if (tmp) hipFree(tmp);
+    if (loc == SLSQP_HOST) HIPCHK(hipStreamSynchronize(h->st));   // the caller's buffers may be reused on return; device callers stay asynchronous on the handle's stream
     h->have_dyn = true;
     return 0;
 }
@@ -671,19 +708,27 @@ extern "C" int slsqp_nominal_solve(slsqp_handle *h, int max_qp, double tol, doub
 extern "C" int slsqp_cl_log(slsqp_handle *h, int max_steps) {
     hipSetDevice(h->dev);
     if (max_steps < 1) return fail("slsqp_cl_log: max_steps must be >= 1");
-    { void *lg[] = {h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_succ, h->lg_it}; for (void *p : lg) if (p) hipFree(p); }
+    HIPCHK(hipStreamSynchronize(h->st));
+    h->log_steps = 0;
+    free_all(h->log_owned);
+    static const char *names[] = {"log_nominal_x", "log_nominal_u", "log_backoff_x", "log_backoff_u", "log_state", "log_u0", "log_success", "log_scp_iterations", "log_primal_infeasibility"};
+    for (const char *nm : names) h->named.erase(nm);
+    h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr;
     const slsqp_dims &d = h->d;
     const size_t B = h->B, S = max_steps, nX = (size_t)(d.N + 1) * d.nx, nU = (size_t)d.N * d.nu;
     int rc = 0;
-    rc |= dalloc(&h->lg_x, B * S * nX); rc |= dalloc(&h->lg_u, B * S * nU); rc |= dalloc(&h->lg_bx, B * S * nX); rc |= dalloc(&h->lg_bu, B * S * nU);
-    rc |= dalloc(&h->lg_state, B * S * d.nx); rc |= dalloc(&h->lg_u0, B * S * d.nu); rc |= dalloc(&h->lg_succ, B * S); rc |= dalloc(&h->lg_it, B * S);
-    if (rc) { h->log_steps = 0; return -1; }
+    auto &ow = h->log_owned;
+    rc |= dalloc(ow, &h->lg_x, B * S * nX); rc |= dalloc(ow, &h->lg_u, B * S * nU); rc |= dalloc(ow, &h->lg_bx, B * S * nX); rc |= dalloc(ow, &h->lg_bu, B * S * nU);
+    rc |= dalloc(ow, &h->lg_state, B * S * d.nx); rc |= dalloc(ow, &h->lg_u0, B * S * d.nu); rc |= dalloc(ow, &h->lg_succ, B * S); rc |= dalloc(ow, &h->lg_it, B * S);
+    rc |= dalloc(ow, &h->lg_pinf, B * S);
+    if (rc) { free_all(ow); h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr; return -1; }
     h->log_steps = max_steps;
     auto reg = [&](const char *nm, void *p, size_t bytes) { h->named[nm] = {p, bytes}; };
     reg("log_nominal_x", h->lg_x, sizeof(double) * S * nX); reg("log_nominal_u", h->lg_u, sizeof(double) * S * nU);
     reg("log_backoff_x", h->lg_bx, sizeof(double) * S * nX); reg("log_backoff_u", h->lg_bu, sizeof(double) * S * nU);
     reg("log_state", h->lg_state, sizeof(double) * S * d.nx); reg("log_u0", h->lg_u0, sizeof(double) * S * d.nu);
     reg("log_success", h->lg_succ, sizeof(int) * S); reg("log_scp_iterations", h->lg_it, sizeof(int) * S);
+    reg("log_primal_infeasibility", h->lg_pinf, sizeof(double) * S);
     return 0;
 }
 
@@ -715,23 +760,31 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
     hipLaunchKernelGGL(k_fill_int, dim3(gbi), dim3(256), 0, h->st, h->scp_active, 1, B);
     hipLaunchKernelGGL(k_fill_int, dim3(gbi), dim3(256), 0, h->st, h->scp_success, 0, B);
     hipLaunchKernelGGL(k_fill_int, dim3(gbi), dim3(256), 0, h->st, h->scp_iters, 0, B);
+    double tj = 0;
+    HIPCHK(hipEventRecord(h->ev[6], h->st));
     if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, nullptr)) return -1;
+    HIPCHK(hipEventRecord(h->ev[7], h->st));
     for (int ii = 0; ii < max_it; ii++) {
         hipLaunchKernelGGL(k_cl_x0arg, dim3(64), dim3(256), 0, h->st, a);
-        if (solve_impl(h, h->x0arg, SLSQP_DEVICE, &o, h->scp_active)) return -1;
-        tq += h->t_qp; ts += h->t_sweep; tt += h->t_total;
+        if (solve_impl(h, h->x0arg, SLSQP_DEVICE, &o, h->scp_active)) return -1;      // ends with a stream synchronisation
+        tq += h->t_qp; ts += h->t_sweep; tt += h->t_total; tj += ev_ms(h->ev[6], h->ev[7]);
         HIPCHK(hipMemsetAsync(h->counter + 2, 0, sizeof(int), h->st));
-        ScpArgs sa{ii, converge ? 1 : 0, o.scp_eps, h->scp_active, h->scp_success, h->scp_iters, h->counter + 2, h->scp_dmax};
+        ScpArgs sa{ii, converge ? 1 : 0, o.scp_eps, h->scp_active, h->scp_success, h->scp_iters, h->counter + 2, h->scp_dmax, h->scp_upd};
         hipLaunchKernelGGL(k_cl_scp_update, dim3(B), dim3(64), 0, h->st, a, sa);
+        if (h->model_id == 0) hipLaunchKernelGGL((k_cl_infeas<0>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
+        else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_infeas<1>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
+        else hipLaunchKernelGGL((k_cl_infeas<2>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
         int nact = 0;
         HIPCHK(hipMemcpyAsync(&nact, h->counter + 2, sizeof(int), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
         if (nact == 0 || ii + 1 == max_it) break;
+        HIPCHK(hipEventRecord(h->ev[6], h->st));
         if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, h->scp_active)) return -1;   // update_jacobian for the next iteration (:138)
+        HIPCHK(hipEventRecord(h->ev[7], h->st));
     }
     if (h->log_steps > 0 && h->cl_steps < h->log_steps) {
         ClLogArgs la{h->B, d.N, d.nx, d.nu, h->log_steps, h->cl_steps, h->Xn, h->Un, h->backoff_x, h->backoff_u, h->scp_success, h->scp_iters,
-                     h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_succ, h->lg_it};
+                     h->pinf, h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_pinf, h->lg_succ, h->lg_it};
         hipLaunchKernelGGL(k_cl_log, dim3(1024), dim3(256), 0, h->st, la);
     }
     if (h->model_id == 0) hipLaunchKernelGGL((k_cl_shift_plant<0>), dim3(gb), dim3(64), 0, h->st, a, 0, 1);
@@ -739,7 +792,7 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
     else hipLaunchKernelGGL((k_cl_shift_plant<2>), dim3(gb), dim3(64), 0, h->st, a, 0, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->st));
-    h->t_qp = tq; h->t_sweep = ts; h->t_total = tt;
+    h->t_qp = tq; h->t_sweep = ts; h->t_total = tt; h->t_jac = tj;
     h->cl_steps++;
     return 0;
 }
@@ -762,16 +815,15 @@ extern "C" int slsqp_qp_update_data_mat(slsqp_handle *h, const double *P_x, cons
     }
     if (A_x) {
         const double *src = A_x;
-        double *tmp = nullptr;
         if (loc == SLSQP_HOST) {
-            HIPCHK(hipMalloc((void **)&tmp, sizeof(double) * (size_t)h->B * nnzA));
-            HIPCHK(hipMemcpy(tmp, A_x, sizeof(double) * (size_t)h->B * nnzA, hipMemcpyHostToDevice));
+            double *tmp = stage_buf(h, sizeof(double) * (size_t)h->B * nnzA);
+            if (!tmp) return -1;
+            HIPCHK(hipMemcpyAsync(tmp, A_x, sizeof(double) * (size_t)h->B * nnzA, hipMemcpyHostToDevice, h->st));
             src = tmp;
         }
         hipLaunchKernelGGL(k_gather_csc, dim3(1024), dim3(256), 0, h->st, h->B, d.N * d.nx * d.nx, nnzA, h->mapA, src, h->A);
         hipLaunchKernelGGL(k_gather_csc, dim3(1024), dim3(256), 0, h->st, h->B, d.N * d.nx * d.nu, nnzA, h->mapB, src, h->Bm);
         HIPCHK(hipStreamSynchronize(h->st));
-        if (tmp) hipFree(tmp);
     }
     return 0;
 }
@@ -782,16 +834,15 @@ extern "C" int slsqp_qp_update_data_vec(slsqp_handle *h, const double *q, const 
     if (q && put(h, h->q, q, sizeof(double) * B * h->n, loc)) return -1;
     if (l && u) {
         const double *dl = l, *du = u;
-        double *tmp = nullptr;
         if (loc == SLSQP_HOST) {
-            HIPCHK(hipMalloc((void **)&tmp, sizeof(double) * 2 * B * h->m));
-            HIPCHK(hipMemcpy(tmp, l, sizeof(double) * B * h->m, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(tmp + B * h->m, u, sizeof(double) * B * h->m, hipMemcpyHostToDevice));
+            double *tmp = stage_buf(h, sizeof(double) * 2 * B * h->m);
+            if (!tmp) return -1;
+            HIPCHK(hipMemcpyAsync(tmp, l, sizeof(double) * B * h->m, hipMemcpyHostToDevice, h->st));
+            HIPCHK(hipMemcpyAsync(tmp + B * h->m, u, sizeof(double) * B * h->m, hipMemcpyHostToDevice, h->st));
             dl = tmp; du = tmp + B * h->m;
         }
         hipLaunchKernelGGL(k_split_lu, dim3(1024), dim3(256), 0, h->st, h->B, h->mb, h->d.nx, dl, du, h->lbg, h->ubg, h->x0val);
         HIPCHK(hipStreamSynchronize(h->st));
-        if (tmp) hipFree(tmp);
     }
     h->have_dyn = true;
     return 0;
@@ -808,17 +859,16 @@ extern "C" int slsqp_qp_solve(slsqp_handle *h, double *x, double *y, int *status
     HIPCHK(hipStreamSynchronize(h->st));
     h->t_total = h->t_qp = ev_ms(h->ev[0], h->ev[1]); h->t_sweep = 0;
     const hipMemcpyKind kd = loc == SLSQP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    if (x) HIPCHK(hipMemcpy(x, h->primal, sizeof(double) * (size_t)h->B * h->n, kd));
+    if (x) HIPCHK(hipMemcpyAsync(x, h->primal, sizeof(double) * (size_t)h->B * h->n, kd, h->st));
     if (y) {
-        double *tmp = nullptr;
-        HIPCHK(hipMalloc((void **)&tmp, sizeof(double) * (size_t)h->B * h->m));
+        double *tmp = stage_buf(h, sizeof(double) * (size_t)h->B * h->m);
+        if (!tmp) return -1;
         hipLaunchKernelGGL(k_join_y, dim3(1024), dim3(256), 0, h->st, h->B, h->mb, h->d.nx, h->dual, h->pin_dual, tmp);
-        HIPCHK(hipStreamSynchronize(h->st));
-        HIPCHK(hipMemcpy(y, tmp, sizeof(double) * (size_t)h->B * h->m, kd));
-        hipFree(tmp);
+        HIPCHK(hipMemcpyAsync(y, tmp, sizeof(double) * (size_t)h->B * h->m, kd, h->st));
     }
-    if (status) HIPCHK(hipMemcpy(status, h->status, sizeof(int) * h->B, kd));
-    if (iters) HIPCHK(hipMemcpy(iters, h->iters, sizeof(int) * h->B, kd));
+    if (status) HIPCHK(hipMemcpyAsync(status, h->status, sizeof(int) * h->B, kd, h->st));
+    if (iters) HIPCHK(hipMemcpyAsync(iters, h->iters, sizeof(int) * h->B, kd, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
     return 0;
 }
 
@@ -831,6 +881,7 @@ extern "C" int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta
     const size_t B = h->B;
     if (put(h, h->eta, eta, sizeof(double) * B * d.N * d.N * d.ni, loc)) return -1;
     if (put(h, h->eta_f, eta_f, sizeof(double) * B * (d.N + 1) * d.ni_f, loc)) return -1;
+    hipLaunchKernelGGL(k_fill_int, dim3((h->B + 255) / 256), dim3(256), 0, h->st, h->stale, 0, h->B);   // eta given by the caller, K written for every instance
     HIPCHK(hipEventRecord(h->ev[0], h->st));
     if (launch_sweep(h, nullptr, h->eta, h->eta_f, 1e-10)) return -1;
     HIPCHK(hipEventRecord(h->ev[1], h->st));
@@ -840,10 +891,11 @@ extern "C" int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta
     HIPCHK(hipStreamSynchronize(h->st));
     h->t_sweep = ev_ms(h->ev[0], h->ev[1]); h->t_total = ev_ms(h->ev[0], h->ev[2]); h->t_qp = 0;
     const hipMemcpyKind kd = loc == SLSQP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    if (K) HIPCHK(hipMemcpy(K, h->K, sizeof(double) * B * d.N * (d.N + 1) * d.nu * d.nx, kd));
-    if (beta) HIPCHK(hipMemcpy(beta, h->beta, sizeof(double) * B * d.N * d.N * d.ni, kd));
-    if (beta_f) HIPCHK(hipMemcpy(beta_f, h->beta_f, sizeof(double) * B * (d.N + 1) * d.ni_f, kd));
-    if (backoff) HIPCHK(hipMemcpy(backoff, h->backoff, sizeof(double) * B * d.N * d.ni, kd));
-    if (backoff_f) HIPCHK(hipMemcpy(backoff_f, h->backoff_f, sizeof(double) * B * d.ni_f, kd));
+    if (K) HIPCHK(hipMemcpyAsync(K, h->K, sizeof(double) * B * d.N * (d.N + 1) * d.nu * d.nx, kd, h->st));
+    if (beta) HIPCHK(hipMemcpyAsync(beta, h->beta, sizeof(double) * B * d.N * d.N * d.ni, kd, h->st));
+    if (beta_f) HIPCHK(hipMemcpyAsync(beta_f, h->beta_f, sizeof(double) * B * (d.N + 1) * d.ni_f, kd, h->st));
+    if (backoff) HIPCHK(hipMemcpyAsync(backoff, h->backoff, sizeof(double) * B * d.N * d.ni, kd, h->st));
+    if (backoff_f) HIPCHK(hipMemcpyAsync(backoff_f, h->backoff_f, sizeof(double) * B * d.ni_f, kd, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
     return 0;
 }

@@ -32,10 +32,6 @@ constexpr int ST_INIT = -1;
 #ifndef NE_MFMA
 #define NE_MFMA 1
 #endif
-// NE_GJ_MFMA: the SPD inverse of the factor sweep as a 4x4-block Gauss-Jordan sweep on the matrix core (wla::spd_inv_blk4_mfma)
-#ifndef NE_GJ_MFMA
-#define NE_GJ_MFMA 0
-#endif
 
 struct Costs {  // batch-constant diagonal weights (device pointers)
     const double *Qd, *Rd, *Qfd;        // diag of Q, R, Qf (P = 2*blkdiag)
@@ -83,6 +79,8 @@ struct QpArgs {
     const double *prox;       // per-instance proximal weight added to the diagonal cost (element b * prox_stride), or NULL
     int prox_stride;
     unsigned long long *inst_launches;   // [0] += 1 per instance forward sweep, [1] += 1 per factorising one (roofline accounting of bench.py)
+    int *qpstat;              // (B,2,8) or NULL: per instance and slot [its, block solves, factorising ones, active inequality rows, started warm,
+    int stat_slot;            //   active-set correction rounds, status, fell back to the interior point]; slot = 0 first QP of a fast-SLS call, 1 its last QP
     int n_refine;             // refinement solves per polish (1 in fp64, 3 with fp32 factorisations)
     double early_ctol;        // tolerance (relative to max(1,|q|inf)) of the look at the un-refined polish solve: its accuracy class
 };
@@ -184,10 +182,6 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             else wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
             wla::wsync();
             STAMP(3);
-#if NE_GJ_MFMA
-            if constexpr (Ld::MFMA) fail |= wla::spd_inv_blk4_mfma<NX>(sY, NX, Lcur, NX, lane);
-            else
-#endif
             fail |= wla::spd_inv_gj<NX>(sY, NX, Lcur, NX, (double *)nullptr, lane);
             STAMP(4);
             double *Lg = g.Linv + (size_t)k * MM;
@@ -518,16 +512,6 @@ __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
     if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { atomicAdd(a.inst_launches + 1, 1ULL); st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
 }
 
-template <int NX, int NU>
-__global__ __launch_bounds__(64) void k_ne_bwd(QpArgs a) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B || (a.run && !a.run[b])) return;
-    const QpState *st = (const QpState *)a.state + b;
-    if ((int)st->phase == P_DONE) return;
-    extern __shared__ double sm[];
-    ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
-}
-
 // first = 1: set up the instance (x0-pin check, starting rhs); else consume the solve of the current phase.
 template <int NX, int NU>
 __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, int lane) {
@@ -700,7 +684,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         }
         for (int o = lane; o < N * NX; o += 64) NUP[o] = (firstp ? 0.0 : NUP[o]) + W[o];
         wla::wsync_mem();
-        const double max_rounds = (s.warm != 0.0) ? (double)a.warm_rounds : 8.0;
+        const double max_rounds = (s.warm > 0.0) ? (double)a.warm_rounds : 8.0;
         bool again = false;
         if (phase == P_POL0 && s.pol_fail == 0.0 && s.pol_round < max_rounds) {
             // cheap look at the un-refined solve: if the active set is visibly wrong (coarse tolerance) correct it now and
@@ -787,9 +771,9 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                     ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
                 }
                 phase = P_POL0;
-            } else if (s.warm != 0.0) {
+            } else if (s.warm > 0.0) {
                 // warm attempt failed: cold start of the interior point (rhs of P_INIT)
-                s.warm = 0.0; s.pol_round = 0.0; s.pol_fail = 0.0;
+                s.warm = -1.0; s.pol_round = 0.0; s.pol_fail = 0.0;      // -1: warm attempt abandoned
         #pragma unroll 4
         for (int e = lane; e < n; e += 64) {
                     const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
@@ -850,7 +834,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         wla::wsync_mem();
         // ---- write-out (reference layouts: primal qp_jit.py:489-490, duals :493-501) ----
         double *pr = a.primal + (size_t)b * n, *du = a.dual + (size_t)b * mb;
-        double csum = 0.0;
+        double csum = 0.0, nact = 0.0;
         const bool ok = (status == 0 || status == 4);   // on failure the previous primal/dual stay (fast_SLS_jit.py:461-464)
         if (ok) {
     #pragma unroll 4
@@ -864,6 +848,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                     yl = ac < 0.0 ? fmax(gr, 0.0) : 0.0;
                 } else { zv = Z[e]; gv = GC[e]; yu = el.fu ? LU[e] : 0.0; yl = el.fl ? LL[e] : 0.0; }
                 pr[e] = zv;
+                nact += (yu > 0.0 ? 1.0 : 0.0) + (yl > 0.0 ? 1.0 : 0.0);
                 csum += 0.5 * el.pd * zv * zv + el.q * zv;
                 const int k = e / NZ, i = e % NZ;
                 if (k < N) { du[k * SR + NX + i] = yu; du[k * SR + NX + NZ + i] = yl; }
@@ -874,7 +859,13 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             for (int o = lane; o < N * NX; o += 64) du[(o / NX) * SR + (o % NX)] = nus[o];
         }
         csum = wla::wave_sum(csum);
+        nact = wla::wave_sum(nact);
         if (lane == 0) {
+            if (a.qpstat) {
+                int *qs = a.qpstat + ((size_t)b * 2 + a.stat_slot) * 8;
+                qs[0] = it; qs[1] = (int)stp->ticks; qs[2] = (int)stp->fticks; qs[3] = (int)nact; qs[4] = (s.warm != 0.0) ? 1 : 0;
+                qs[5] = (int)s.pol_round; qs[6] = status; qs[7] = (s.warm < 0.0) ? 1 : 0;
+            }
             if (ok) a.cost[b] = csum;
             a.status[b] = status;
             a.iters[b] = it;
@@ -973,11 +964,12 @@ __global__ void k_set_bounds(BoundsArgs a) {
 // ------------------------------------------------------------------------------------------------
 // evaluate_dual_eta (fast_SLS_jit.py:475-487)
 // ------------------------------------------------------------------------------------------------
-struct EtaArgs { int B, N, NX, NI, NIF; const double *dual, *beta, *beta_f; const int *run; double *eta, *eta_f; double eps; };
+struct EtaArgs { int B, N, NX, NI, NIF; const double *dual, *beta, *beta_f; const int *run; double *eta, *eta_f; double eps; int *stale; };
 __global__ void k_eta(EtaArgs a) {
     const int b = blockIdx.x;
     if (a.run && !a.run[b]) return;
     const int SR = a.NX + a.NI, mb = a.N * SR + a.NIF;
+    if (a.stale && threadIdx.x == 0) a.stale[b] &= ~1;   // every entry with j <= k is rewritten below; the others are never written by anyone (zero)
     const double *du = a.dual + (size_t)b * mb;
     const double *be = a.beta + (size_t)b * a.N * a.N * a.NI;
     double *et = a.eta + (size_t)b * a.N * a.N * a.NI;
@@ -1389,13 +1381,14 @@ struct ClArgs {
 //   converge mode and |delta|inf < eps -> scp_success = 1, the instance leaves the loop BEFORE the next linearisation (:123-132)
 //   RTI mode                         -> scp_success = success of the last step                             (:148)
 // One wave per instance; n_active counts the instances that go on.
-struct ScpArgs { int ii, converge; double eps; int *active, *scp_success, *scp_iters, *n_active; double *dmax; };
+struct ScpArgs { int ii, converge; double eps; int *active, *scp_success, *scp_iters, *n_active; double *dmax; int *updated; };
 __global__ __launch_bounds__(64) void k_cl_scp_update(ClArgs a, ScpArgs s) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B || !s.active[b]) return;
+    if (b >= a.B) return;
+    if (!s.active[b]) { if (lane == 0) s.updated[b] = 0; return; }
     const int NZ = a.NX + a.NU, n = NZ * a.N + a.NX;
     if (!a.success[b]) {
-        if (lane == 0) { s.active[b] = 0; s.scp_success[b] = 0; s.scp_iters[b] = s.ii; }
+        if (lane == 0) { s.active[b] = 0; s.scp_success[b] = 0; s.scp_iters[b] = s.ii; s.updated[b] = 0; }
         return;
     }
     const double *d = a.primal + (size_t)b * n;
@@ -1410,6 +1403,7 @@ __global__ __launch_bounds__(64) void k_cl_scp_update(ClArgs a, ScpArgs s) {
     dm = wla::wave_max(dm);
     if (lane == 0) {
         s.dmax[b] = dm;
+        s.updated[b] = 1;
         s.scp_iters[b] = s.ii;
         if (s.converge) {
             if (dm < s.eps) { s.scp_success[b] = 1; s.active[b] = 0; }
@@ -1424,13 +1418,33 @@ __global__ void k_cl_x0arg(ClArgs a) {
         a.x0arg[t] = a.Xn[(size_t)b * (a.N + 1) * a.NX + i] - a.xmeas[t];
     }
 }
+// primal_infeasibility of SCP_SLS.socp_step (solver/SCP_SLS_jit.py:449-456): the signed maximum over stages and components of
+// ddyn(x_k,u_k) - x_{k+1} along the nominal just updated.  One wave per instance, lane k = stage k (N <= 64).
+template <int MODEL>
+__global__ __launch_bounds__(64) void k_cl_infeas(ClArgs a, const int *updated, double *pinf) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
+    const int b = blockIdx.x, k = threadIdx.x;
+    if (b >= a.B || !updated[b]) return;
+    const double *X = a.Xn + (size_t)b * (a.N + 1) * NX, *U = a.Un + (size_t)b * a.N * NU;
+    double mx = -1e300;
+    if (k < a.N) {
+        double x[NX], u[NU], xp[NX];
+        for (int i = 0; i < NX; i++) x[i] = X[(size_t)k * NX + i];
+        for (int i = 0; i < NU; i++) u[i] = U[(size_t)k * NU + i];
+        dyn::ddyn<MODEL, double>(x, u, xp);
+        for (int i = 0; i < NX; i++) mx = fmax(mx, xp[i] - X[(size_t)(k + 1) * NX + i]);
+    }
+    mx = wla::wave_max(mx);
+    if (k == 0) pinf[b] = mx;
+}
 // device-side log of a closed-loop run (what the scripts store per MPC step, expe/main_rocket_robust_closed_loop.py:160-178): entry `step`
 // of (B, S, ...) buffers, so a whole Monte-Carlo run needs no host round trip per step
 struct ClLogArgs {
     int B, N, NX, NU, S, step;
     const double *Xn, *Un, *bx, *bu;
     const int *success, *scp_iters;
-    double *lx, *lu, *lbx, *lbu, *lstate, *lu0;
+    const double *pinf;
+    double *lx, *lu, *lbx, *lbu, *lstate, *lu0, *lpinf;
     int *lsucc, *lit;
 };
 __global__ void k_cl_log(ClLogArgs a) {
@@ -1450,7 +1464,7 @@ __global__ void k_cl_log(ClLogArgs a) {
             if (o < a.NU) a.lu0[e * a.NU + o] = v;
         } else if ((o -= nU) < nX) a.lbx[e * nX + o] = a.bx[(size_t)b * nX + o];
         else { o -= nX; a.lbu[e * nU + o] = a.bu[(size_t)b * nU + o]; }
-        if (t % per == 0) { a.lsucc[e] = a.success[b]; a.lit[e] = a.scp_iters[b]; }
+        if (t % per == 0) { a.lsucc[e] = a.success[b]; a.lit[e] = a.scp_iters[b]; a.lpinf[e] = a.pinf[b]; }
     }
 }
 // warm-start shift (SCP_SLS_jit.py:508-518): x_k <- x_{k+1}, u_k <- u_{k+1}, u_{N-1} kept, x_N <- ddyn(x_N, u_{N-1});

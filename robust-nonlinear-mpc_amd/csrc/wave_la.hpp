@@ -52,32 +52,6 @@ __device__ __forceinline__ int wave_or(int v) {
     return v;
 }
 
-// C(MxN) = alpha * op(A) op(B) + beta * C ; row-major, leading dims given; op = transpose when TA/TB.
-// Each lane owns outputs o = lane, lane+64, ... ; with 1x2 register blocking along N when N is even-ish.
-template <int M, int N, int K, bool TA, bool TB>
-__device__ __forceinline__ void gemm(const double *A, int lda, const double *B, int ldb, double *C, int ldc,
-                                     double alpha, double beta, int lane) {
-    constexpr int TOT = M * N;
-#pragma unroll
-    for (int o0 = 0; o0 < TOT; o0 += 64) {
-        const int o = o0 + lane;
-        if (o < TOT) {
-            const int i = o / N, j = o % N;
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                const double a = TA ? A[k * lda + i] : A[i * lda + k];
-                const double b = TB ? B[j * ldb + k] : B[k * ldb + j];
-                s = fma(a, b, s);
-            }
-            double r = alpha * s;
-            if (beta != 0.0) r += beta * C[i * ldc + j];
-            C[i * ldc + j] = r;
-        }
-    }
-}
-
-
 // C(MxN) = alpha * A(MxK) * B(NxK)' with RBxCB register blocking per lane (one pass, needs ceil(M/RB)*ceil(N/CB) <= 64).
 // Out-of-range rows/cols are clamped on load and masked on store.
 template <int M, int N, int K, int RB, int CB, typename T>
@@ -329,17 +303,6 @@ __device__ __forceinline__ void build_Y_mfma(const double *A, const double *pix,
     }
 }
 
-// y(M) = op(A)(MxK) x(K)  (lane i < M computes row i).  TA: A stored KxM.
-template <int M, int K, bool TA, typename T>
-__device__ __forceinline__ T matvec_row(const T *A, int lda, const T *x, int lane) {
-    T s = T(0);
-    if (lane < M) {
-#pragma unroll
-        for (int k = 0; k < K; k++) s = fma(TA ? A[k * lda + lane] : A[lane * lda + k], x[k], s);
-    }
-    return s;
-}
-
 // y(M) = op(A)(MxK) x(K) with the sum over k split three ways across lane groups (lane = i + M g, g = 0..2) and combined through the
 // crossbar: a dependent chain of ceil(K/3) FMAs instead of K, and a third of the LDS reads per lane.  Valid in lanes < M.
 template <int M, int K, bool TA, typename T>
@@ -461,168 +424,6 @@ __device__ __forceinline__ int spd_inv_gj(const R *Y, int ld, R *Dinv, int ldi, 
         if (i0 < M && l1 < M && bi != bj) { Dinv[i0 * ldi + l1] = -a01; Dinv[l1 * ldi + i0] = -a01; }
         if (i1 < M && l0 < M) { Dinv[i1 * ldi + l0] = -a10; Dinv[l0 * ldi + i1] = -a10; }
         if (i1 < M && l1 < M) { Dinv[i1 * ldi + l1] = -a11; Dinv[l1 * ldi + i1] = -a11; }
-    }
-    wsync();
-    return fail;
-}
-
-// Inverse of the MxM SPD matrix Y (13 <= M <= 17, lower triangle in LDS) by a Gauss-Jordan sweep with 4x4 pivot blocks whose rank-4 updates run
-// on the fp64 matrix core.  The 16x16 core lives in the MFMA accumulator layout for the whole sweep (lane l: column l&15, rows (l>>4) + 4r in
-// register r); per pivot block J: the 4x4 pivot is read with v_readlane and inverted redundantly by every lane (two nested 2x2 Schur
-// complements), W = A[:,J] P^-1 is formed from four crossbar gathers, one v_mfma_f64_16x16x4 applies A -= W A[J,:], and the pivot
-// row / column / block are patched (A[J,:] <- P^-1 A[J,:] = W', A[:,J] <- W, A[J,J] <- -P^-1).  After four blocks the registers hold -A^-1.
-// M = 17: the 17th row / column is added by bordering (one matrix-vector product, a rank-1 update).  M < 16: identity padding.
-// Half the instructions of spd_inv_gj.  Returns non-zero (wave-uniform) if a pivot was not positive.
-template <int M>
-__device__ __forceinline__ int spd_inv_blk4_mfma(const double *Y, int ld, double *Dinv, int ldi, int lane) {
-    static_assert(M >= 13 && M <= 17, "16x16 core (+1)");
-    constexpr int MC = M < 16 ? M : 16;
-    const int j = lane & 15, a = lane >> 4;
-    int fail = 0;
-    mfma_d4 acc;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int i = a + 4 * r;
-        const int hi = max(i, j), lo = min(i, j);
-        const double v = Y[min(hi, MC - 1) * ld + min(lo, MC - 1)];
-        acc[r] = (i < MC && j < MC) ? v : ((i == j) ? 1.0 : 0.0);
-    }
-    auto inv2 = [&](double p00, double p10, double p11, double &q00, double &q10, double &q11) {   // SPD 2x2, as in spd_inv_gj
-        double d1 = p00;
-        if (!(d1 > 1e-300)) { fail = 1; d1 = 1e-300; }
-        const double r1 = fast_rcp(d1), bp = p10 * r1;
-        double d2 = fma(-p10, bp, p11);
-        if (!(d2 > 1e-300)) { fail = 1; d2 = 1e-300; }
-        const double r2 = fast_rcp(d2);
-        q11 = r2; q10 = -bp * r2; q00 = fma(bp * bp, r2, r1);
-    };
-#pragma unroll
-    for (int rb = 0; rb < 4; rb++) {
-        // pivot block P = A[J,J], J = 4rb..4rb+3 (lower triangle; uniform)
-        double p[4][4];
-#pragma unroll
-        for (int x = 0; x < 4; x++)
-#pragma unroll
-            for (int y = 0; y <= x; y++) { p[x][y] = readlane_d(acc[rb], 16 * x + 4 * rb + y); p[y][x] = p[x][y]; }
-        // Q = P^-1 by 2x2 blocks: P = [[A,B'],[B,C]]
-        double a00, a10, a11;
-        inv2(p[0][0], p[1][0], p[1][1], a00, a10, a11);                       // Ai = A^-1
-        // U = B Ai (2x2), B = p[2..3][0..1]
-        const double u00 = fma(p[2][0], a00, p[2][1] * a10), u01 = fma(p[2][0], a10, p[2][1] * a11);
-        const double u10 = fma(p[3][0], a00, p[3][1] * a10), u11 = fma(p[3][0], a10, p[3][1] * a11);
-        // S = C - U B'
-        const double s00 = fma(-u00, p[2][0], fma(-u01, p[2][1], p[2][2]));
-        const double s10 = fma(-u10, p[2][0], fma(-u11, p[2][1], p[3][2]));
-        const double s11 = fma(-u10, p[3][0], fma(-u11, p[3][1], p[3][3]));
-        double z00, z10, z11;
-        inv2(s00, s10, s11, z00, z10, z11);                                   // Z = S^-1
-        // Q = [[Ai + U' Z U, -U' Z], [-Z U, Z]]
-        const double zu00 = fma(z00, u00, z10 * u10), zu01 = fma(z00, u01, z10 * u11);   // Z U (2x2)
-        const double zu10 = fma(z10, u00, z11 * u10), zu11 = fma(z10, u01, z11 * u11);
-        double q[4][4];
-        q[2][2] = z00; q[3][2] = z10; q[2][3] = z10; q[3][3] = z11;
-        q[2][0] = -zu00; q[2][1] = -zu01; q[3][0] = -zu10; q[3][1] = -zu11;
-        q[0][2] = q[2][0]; q[1][2] = q[2][1]; q[0][3] = q[3][0]; q[1][3] = q[3][1];
-        q[0][0] = fma(u00, zu00, fma(u10, zu10, a00));
-        q[1][0] = fma(u01, zu00, fma(u11, zu10, a10));
-        q[1][1] = fma(u01, zu01, fma(u11, zu11, a11));
-        q[0][1] = q[1][0];
-        // C[i][m] = A[i][4rb+m] = A[4rb+m][i] (symmetry): register rb of lane 16m + i, i = lane&15
-        double cm[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) cm[m] = bperm_d(acc[rb], 16 * m + j);
-        // W[i][k] = sum_m C[i][m] Q[m][k] for this lane's k = lane>>4
-        double wk[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) wk[k] = fma(cm[0], q[0][k], fma(cm[1], q[1][k], fma(cm[2], q[2][k], cm[3] * q[3][k])));
-        const double w = (a == 0) ? wk[0] : ((a == 1) ? wk[1] : ((a == 2) ? wk[2] : wk[3]));   // W[i = lane&15][k = lane>>4]
-        // A -= W A[J,:]   (b operand: A[4rb+k][j] is this lane's own register rb)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-w, acc[rb], acc, 0, 0, 0);
-        // patches
-        const bool inJ = (j >> 2) == rb;
-        const int c = j & 3;
-        // pivot column, rows outside J: A[i][4rb+c] <- W[i][c] = a-operand value of lane 16c + i
-        double wcol[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) wcol[r] = bperm_d(w, 16 * c + a + 4 * r);
-        // -Q[a][c] for the pivot block
-        double qa[4];
-#pragma unroll
-        for (int y = 0; y < 4; y++) qa[y] = (a == 0) ? q[0][y] : ((a == 1) ? q[1][y] : ((a == 2) ? q[2][y] : q[3][y]));
-        const double qac = (c == 0) ? qa[0] : ((c == 1) ? qa[1] : ((c == 2) ? qa[2] : qa[3]));
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (r == rb) acc[r] = inJ ? -qac : w;          // pivot row: P^-1 A[J,j] = W[j][a] = this lane's own w; pivot block: -P^-1
-            else acc[r] = inJ ? wcol[r] : acc[r];
-        }
-    }
-    // acc = -inv(core)
-    if constexpr (M <= 16) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) { const int i = a + 4 * r; if (i < MC && j < MC) Dinv[i * ldi + j] = -acc[r]; }
-    } else {
-        // bordering: A17 = [[A, y],[y', d]],  u = A^-1 y,  s = d - y'u,  inv = [[A^-1 + u u'/s, -u/s], [-u'/s, 1/s]]
-        const double yj = Y[16 * ld + j];
-        double part = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; r++) part = fma(-acc[r], Y[16 * ld + a + 4 * r], part);    // sum over this lane's rows of A^-1[i][j] y[i]
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);                                                      // u[j], in the four lanes of column j
-        const double uj = part;
-        double dot = yj * uj;                                                              // y'u: sum over the 16 columns of a lane group
-        dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4); dot += __shfl_xor(dot, 8);
-        double sden = Y[16 * ld + 16] - dot;
-        if (!(sden > 1e-300)) { fail = 1; sden = 1e-300; }
-        const double zz = fast_rcp(sden);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int i = a + 4 * r;
-            const double ui = bperm_d(uj, i);                                              // u[i] from lane i (column i, group 0)
-            Dinv[i * ldi + j] = fma(zz * ui, uj, -acc[r]);
-        }
-        if (a == 0) { const double x = -zz * uj; Dinv[16 * ldi + j] = x; Dinv[j * ldi + 16] = x; }
-        if (lane == 0) Dinv[16 * ldi + 16] = zz;
-    }
-    wsync();
-    return fail;
-}
-
-// Lower Cholesky of the MxM SPD matrix Y (lower triangle read from LDS), then Linv = L^{-1} (full MxM written to LDS, upper
-// part zero).  Row i of the factor lives in lane i's registers; pivots, columns and the rows needed by the triangular
-// inverse are broadcast with v_readlane (SGPR operands of the FMAs), so the whole factorisation issues no LDS traffic and
-// no s_waitcnt between its 17 dependent steps.  Returns non-zero (wave-uniform) if a pivot was not positive (clamped).
-template <int M>
-__device__ __forceinline__ int chol_inv(const double *Y, int ld, double *Linv, int ldi, double * /*col*/, int lane) {
-    double row[M], rdiag[M];
-    const bool act = lane < M;
-#pragma unroll
-    for (int c = 0; c < M; c++) row[c] = (act && c <= lane) ? Y[lane * ld + c] : 0.0;
-    int fail = 0;
-#pragma unroll
-    for (int j = 0; j < M; j++) {
-        double d = readlane_d(row[j], j);
-        if (!(d > 1e-300)) { fail = 1; d = 1e-300; }
-        const double rs = fast_rsq(d);
-        rdiag[j] = rs;                                  // 1 / L[j][j]
-        row[j] = (lane == j) ? d * rs : row[j] * rs;    // lanes < j hold zeros there
-#pragma unroll
-        for (int l = j + 1; l < M; l++) {
-            const double clj = readlane_d(row[j], l);   // L[l][j]
-            if (lane >= l) row[l] = fma(-row[j], clj, row[l]);
-        }
-    }
-    // inverse: lane c computes column c of X = L^{-1};  L[i][m] = row[m] of lane i
-    double x[M];
-#pragma unroll
-    for (int i = 0; i < M; i++) {
-        double s = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-        for (int m = 0; m < i; m++) s = fma(-readlane_d(row[m], i), x[m], s);   // x[m] = 0 for m < c
-        x[i] = (act && i >= lane) ? s * rdiag[i] : 0.0;
-    }
-    if (act) {
-#pragma unroll
-        for (int i = 0; i < M; i++) Linv[i * ldi + lane] = x[i];
     }
     wsync();
     return fail;

@@ -192,9 +192,9 @@ class BatchedFastSLS:
         return out
 
     def timing_ms(self):
-        t = np.zeros(4)
+        t = np.zeros(5)
         self.lib.slsqp_last_timing(self.h, _ptr(t))
-        return dict(total=t[0], qp=t[1], sweep=t[2], other=t[3])
+        return dict(total=t[0], qp=t[1], sweep=t[2], other=t[3], jac=t[4])
 
     def kernel_timing(self):
         """(total ms, launches) of the dominant kernel k_ne_fwd since the last call (HIP events on the handle's stream)."""

@@ -59,7 +59,7 @@ def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise
     for key, v in parts[0].items():
         if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == cuts[0][1] - cuts[0][0] and key not in ("t_jac", "t_qp", "t_riccati"):
             out[key] = np.concatenate([p[key] for p in parts], axis=0)
-        elif key in ("t_qp", "t_riccati"):
+        elif key in ("t_qp", "t_riccati", "t_jac"):
             out[key] = np.max(np.stack([p[key] for p in parts]), axis=0)      # slices run concurrently
         else:
             out[key] = v

@@ -1,0 +1,34 @@
+"""Dump the QPs a rocket closed loop actually solves (for CPU prototyping of active-set strategies): for consecutive closed-loop steps the problem
+data of the step's last linearisation, the tightened bounds of QP #2, its solution and the per-QP statistics.  Writes gpurun_out/cl_qps.npz."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
+m = get_model("rocket")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+scale = float(sys.argv[3]) if len(sys.argv) > 3 else 0.3
+N = 20
+x0 = m.x_ref + scale * (m.extra["x0"] - m.x_ref)
+W = np.stack([disturbance_stream(s, steps, m.nx) for s in range(B)], axis=1)
+cl = ClosedLoopMPC(m, N, B)
+cl.reset(np.tile(x0, (B, 1)), solve_nominal=True, continuation=2 if scale > 0.6 else 1)
+f = cl.f
+nz = m.nx + m.nu
+n, mb = nz * N + m.nx, N * (m.nx + m.ni) + m.ni_f
+out = {}
+for i in range(steps):
+    cl.step(W[i], fetch=False)
+    for k, shp in (("A", (N, m.nx, m.nx)), ("Bm", (N, m.nx, m.nu)), ("c", (N, m.nx)), ("g", (N, m.ni)), ("gN", (m.ni_f,)), ("q", (n,)), ("x0_arg", (m.nx,)),
+                   ("ubg", (mb,)), ("primal_vec", (n,)), ("dual_vec", (mb,)), ("backoff", (N, m.ni)), ("backoff_f", (m.ni_f,))):
+        out[f"{k}_{i}"] = f.get(k, shp)
+    out[f"qp_stats_{i}"] = f.get("qp_stats", (2, 8), np.int32)
+    out[f"success_{i}"] = f.get("scp_success", (), np.int32)
+    qs = out[f"qp_stats_{i}"]
+    print(f"step {i}: success {out[f'success_{i}'].mean():.3f} | QP1 its>0 {np.mean(qs[:,0,0]>0):.3f} ticks {qs[:,0,1].mean():.1f} nact {qs[:,0,3].mean():.1f} max {qs[:,0,3].max()} warm {qs[:,0,4].mean():.2f} fb {qs[:,0,7].mean():.3f}"
+          f" | QP2 its>0 {np.mean(qs[:,1,0]>0):.3f} ticks {qs[:,1,1].mean():.1f} nact {qs[:,1,3].mean():.1f} max {qs[:,1,3].max()} fb {qs[:,1,7].mean():.3f}", flush=True)
+cl.close()
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+np.savez_compressed(os.path.join(ROOT, "gpurun_out", "cl_qps.npz"), **out)
+print("wrote cl_qps.npz")

@@ -223,6 +223,69 @@ def dyn_case(name, seed, npts=12):
     )
 
 
+def dyn_script_case(name, seed):
+    """Points where the closed loops actually run: along roll-outs from the scripts' own initial states
+    (expe/main_rocket_robust_closed_loop.py:110-126, main_pendulum...:96, the quadrotor script's random x0 recipe :82-90 with a seeded
+    generator), under zero / bound / random bounded inputs, and at saturated actuator states (rocket servo angles +-1, where the
+    gimbal linkage's atan/sqrt branch is far from its neutral point)."""
+    m, *_, x_ref, u_ref = model_setup(name)
+    rng = np.random.default_rng(seed)
+    g = np.asarray(m.g, dtype=float)
+    nz = m.nx + m.nu
+    x_ub, u_ub, x_lb, u_lb = g[:m.nx], g[m.nx:nz], -g[nz:nz + m.nx], -g[nz + m.nx:]
+    if name == "rocket":
+        x0 = np.array([1.75729, 4.15951, 4.72757, -0.18913, -0.38367, -0.08697, -0.79487, 0.00768, -0.21110, -0.56883,
+                       -0.12752, -0.58026, -0.76542, 0.20555, 0.54610, -0.40116, -0.35401])
+        starts = [x0, x_ref + 0.5 * (x0 - x_ref), x_ref + 0.3 * (x0 - x_ref)]
+        steps = 10
+    elif name == "quadrotor":
+        D = np.array([2.0] * 3 + [1.0] * 3 + [0.0] + [0.1] * 3 + [0.5] * 3)
+        starts = []
+        for _ in range(3):
+            x = x_ref + D * rng.uniform(-1, 1, m.nx)
+            x[6:10] /= np.linalg.norm(x[6:10])
+            starts.append(x)
+        steps = 10
+    else:
+        starts = [np.array([0.5, 0.5, 0.0, 0.0]), np.array([-0.5, 1.0, 0.4, -0.3])]
+        steps = 15
+    X, U = [], []
+    for x0 in starts:
+        for mode in ("ref", "rand"):
+            x = np.array(x0, dtype=float)
+            for k in range(steps):
+                u = u_ref.copy() if mode == "ref" else u_lb + (u_ub - u_lb) * rng.uniform(0, 1, m.nu)
+                X.append(x.copy()); U.append(u)
+                x = np.asarray(m.ddyn(x, u), dtype=float).reshape(-1)
+                if not np.all(np.isfinite(x)) or np.max(np.abs(x)) > 1e3:
+                    break
+    # actuator / input corners
+    if name == "rocket":
+        for s1 in (-1.0, 1.0):
+            for s2 in (-1.0, 1.0):
+                x = starts[0] + 0.05 * rng.uniform(-1, 1, m.nx)
+                x[15], x[16] = s1, s2
+                u = np.where(rng.uniform(size=m.nu) < 0.5, u_lb, u_ub)
+                X.append(x); U.append(u)
+                x = x_ref + 0.1 * rng.uniform(-1, 1, m.nx)
+                x[15], x[16] = s1, s2
+                x[13] = rng.choice([-50.0, 50.0]) * 0.2
+                X.append(x); U.append(np.zeros(m.nu))
+    else:
+        for _ in range(4):
+            X.append(x_ref + 0.5 * rng.uniform(-1, 1, m.nx) * np.minimum(x_ub, 2.0))
+            U.append(np.where(rng.uniform(size=m.nu) < 0.5, u_lb, u_ub))
+    X, U = np.stack(X), np.stack(U)
+    npts = X.shape[0]
+    ode = np.stack([np.asarray(m.ode(X[i], U[i]), dtype=float).reshape(-1) for i in range(npts)])
+    ddyn = np.stack([np.asarray(m.ddyn(X[i], U[i]), dtype=float).reshape(-1) for i in range(npts)])
+    A = np.zeros((npts, m.nx, m.nx))
+    B = np.zeros((npts, m.nx, m.nu))
+    for i in range(npts):
+        A[i], B[i] = fd_jac(m, X[i], U[i])
+    return dict(X=X, U=U, ode=ode, ddyn=ddyn, A_fd=A, B_fd=B, dims=np.array([m.nx, m.nu, m.nw, m.ni, m.ni_f]))
+
+
 def riccati_case(seed):
     from solver.ocp import OCP  # importable as-is (numpy only)
 
@@ -257,6 +320,9 @@ def main():
     for name in ("pendulum", "quadrotor", "rocket"):
         np.savez_compressed(os.path.join(OUT, f"dyn_{name}.npz"), **dyn_case(name, 7))
         print("wrote dyn", name)
+        d = dyn_script_case(name, 11)
+        np.savez_compressed(os.path.join(OUT, f"dyn_{name}_script.npz"), **d)
+        print("wrote dyn script", name, d["X"].shape, "max |ddyn|", float(np.abs(d["ddyn"]).max()))
     np.savez_compressed(os.path.join(OUT, "riccati_lq.npz"), **riccati_case(3))
     # numpy legacy RNG stream used by expe/main_rocket_robust_closed_loop.py:30,180 (np.random.seed(0);
     # w = 2*rand(17)-1 per closed-loop step): reproducible with numpy alone, committed for convenience.

@@ -117,38 +117,20 @@ def run_gpu_fastsls(insts, rti_steps=1, solver=None):
 
 
 # ---- closed-loop oracle (restates SCP_SLS.solve / socp_step / reset_warm_start around the oracle fast-SLS) ------------------
-def _dynlib():
-    import ctypes as C
-    import subprocess
-    from conftest import ROOT
-    so = os.path.join(ROOT, "tests", "_build", "libdyn_host.so")
-    src = os.path.join(ROOT, "tests", "dyn_host.cpp")
-    hdr = os.path.join(ROOT, "robust-nonlinear-mpc_amd", "csrc", "dynamics.hpp")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        os.makedirs(os.path.dirname(so), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
-    return C.CDLL(so)
-
-
 def host_ddyn(mid, x, u):
-    import ctypes as C
-    lib = _dynlib()
-    x, u, o = np.ascontiguousarray(x, dtype=float), np.ascontiguousarray(u, dtype=float), np.zeros(len(x))
-    lib.dyn_ddyn(mid, x.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p))
-    return o
+    """RK4 plant step by the INDEPENDENT numpy restatement (oracle/dyn_oracle.py), not by the product's csrc/dynamics.hpp: the
+    closed-loop oracle below and the NLP certificate of the GPU tests share no dynamics code with the library under test."""
+    from oracle import dyn_oracle as DO
+    return DO.ddyn(mid, np.asarray(x, dtype=float), np.asarray(u, dtype=float))
 
 
 def host_jac(mid, x, u):
-    import ctypes as C
-    lib = _dynlib()
-    x, u = np.ascontiguousarray(x, dtype=float), np.ascontiguousarray(u, dtype=float)
-    A, B, f = np.zeros((len(x), len(x))), np.zeros((len(x), len(u))), np.zeros(len(x))
-    p = lambda a: a.ctypes.data_as(C.c_void_p)
-    lib.dyn_jac(mid, p(x), p(u), p(A), p(B), p(f))
-    return A, B, f
+    """A, B (complex-step derivatives of the numpy restatement), f = ddyn(x,u)."""
+    from oracle import dyn_oracle as DO
+    return DO.jac(mid, np.asarray(x, dtype=float), np.asarray(u, dtype=float))
 
 
-def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=None, scp_eps=1e-10, max_scp_iter=100):
+def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=None, scp_eps=1e-10, max_scp_iter=100, X_nom=None, U_nom=None):
     """Single-instance CPU closed loop: SCP_SLS.solve (solver/SCP_SLS_jit.py:65-152) with the zero-order roll-out initialiser,
     reset_warm_start (:500-551) and the plant update of the closed-loop scripts."""
     from oracle import oracle as O
@@ -157,13 +139,16 @@ def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=Non
     fs = O.OracleFastSLS(d, m.G, m.Gf, m.g, m.gf, E, m.Q, m.R, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, settings or O.tight_settings())
     fs.set_rti_steps(sls_steps)
     mid = m.model_id
-    X = np.zeros((N + 1, m.nx)); U = np.tile(m.u_ref, (N, 1))
-    X[0] = x0
-    for k in range(N):
-        X[k + 1] = host_ddyn(mid, X[k], U[k])
+    if X_nom is not None:         # caller's first nominal (the role of IPOPT's in SCP_SLS.solve_nominal_trajectory, SCP_SLS_jit.py:161-188)
+        X, U = np.array(X_nom, dtype=float), np.array(U_nom, dtype=float)
+    else:
+        X = np.zeros((N + 1, m.nx)); U = np.tile(m.u_ref, (N, 1))
+        X[0] = x0
+        for k in range(N):
+            X[k + 1] = host_ddyn(mid, X[k], U[k])
     Hd = np.concatenate([np.concatenate([np.diag(m.Q), np.diag(m.R)])] * N + [np.diag(m.Qf)])
     xm = np.asarray(x0, dtype=float).copy()
-    log = dict(state=[], u0=[], nominal_x=[], nominal_u=[], backoff_x=[], success=[], scp_iterations=[])
+    log = dict(state=[], u0=[], nominal_x=[], nominal_u=[], backoff_x=[], success=[], scp_iterations=[], primal_infeasibility=[])
     converge = rti is None or rti <= 0          # SCP_SLS default rti = -1: until |delta|inf < epsilon_convergence (SCP_SLS_jit.py:113-135)
     for i in range(steps):
         if i > 0:
@@ -195,6 +180,8 @@ def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=Non
         if converge:
             ok = ok and converged
         log["scp_iterations"].append(it_used)
+        # SCP_SLS.socp_step's primal_infeasibility = max_k,i (f(x_k,u_k) - x_{k+1})_i of the updated nominal (SCP_SLS_jit.py:449-456), signed max
+        log["primal_infeasibility"].append(max(float(np.max(host_ddyn(mid, X[k], U[k]) - X[k + 1])) for k in range(N)))
         log["state"].append(X[0].copy()); log["u0"].append(U[0].copy()); log["nominal_x"].append(X.copy()); log["nominal_u"].append(U.copy())
         log["backoff_x"].append(np.array(sol["backoff_x"]) if ok else None); log["success"].append(ok)
         xm = host_ddyn(mid, xm, U[0]) + (m.E @ W[i] if W is not None else 0.0)

@@ -1,6 +1,10 @@
-"""Pins csrc/dynamics.hpp (host instantiation) against values produced by the reference's own ODE / RK4 source
-(tests/golden/dyn_*.npz): ode and ddyn to 1e-12, forward-mode AD Jacobians against central differences of the reference's
-ddyn to 1e-6 (the differences themselves are only ~1e-8 accurate)."""
+"""Pins the two restatements of the plants against values produced by the reference's own ODE / RK4 source
+(tests/golden/dyn_*.npz: near neutral; dyn_*_script.npz: along roll-outs from the scripts' initial states and at saturated actuators):
+  * csrc/dynamics.hpp (product; host instantiation through tests/dyn_host.cpp): ode and ddyn to 1e-12, forward-mode AD Jacobians against
+    central differences of the reference's ddyn to 1e-6 (the differences themselves are only ~1e-8 accurate),
+  * oracle/dyn_oracle.py (test infrastructure, numpy, complex-step Jacobians): the same,
+and the two against each other: AD vs complex step agree to 1e-10 relative -- two independent exact differentiation methods of two
+independent restatements, which pins the Jacobians far below what the finite differences of the fixtures can."""
 import ctypes as C
 import os
 import subprocess
@@ -9,6 +13,9 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT
+from oracle import dyn_oracle as DO
+
+FIXTURES = ["dyn_{}.npz", "dyn_{}_script.npz"]
 
 
 @pytest.fixture(scope="module")
@@ -26,19 +33,43 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _scale(v):
+    return max(1.0, float(np.max(np.abs(v))))
+
+
+@pytest.mark.parametrize("fixture", FIXTURES)
 @pytest.mark.parametrize("name,mid", [("pendulum", 0), ("quadrotor", 1), ("rocket", 2)])
-def test_ode_ddyn_and_jacobians(dynlib, name, mid):
-    g = dict(np.load(os.path.join(GOLDEN, f"dyn_{name}.npz")))
+def test_ode_ddyn_and_jacobians(dynlib, name, mid, fixture):
+    g = dict(np.load(os.path.join(GOLDEN, fixture.format(name))))
     nx, nu = int(g["dims"][0]), int(g["dims"][1])
     for i in range(g["X"].shape[0]):
         x, u = np.ascontiguousarray(g["X"][i]), np.ascontiguousarray(g["U"][i])
         o = np.zeros(nx)
         dynlib.dyn_ode(mid, _p(x), _p(u), _p(o))
-        assert np.allclose(o, g["ode"][i], rtol=1e-12, atol=1e-12)
+        assert np.allclose(o, g["ode"][i], rtol=1e-12, atol=1e-12 * _scale(g["ode"][i]))
         dynlib.dyn_ddyn(mid, _p(x), _p(u), _p(o))
-        assert np.allclose(o, g["ddyn"][i], rtol=1e-12, atol=1e-13)
+        assert np.allclose(o, g["ddyn"][i], rtol=1e-12, atol=1e-13 * _scale(g["ddyn"][i]))
         A, B, f = np.zeros((nx, nx)), np.zeros((nx, nu)), np.zeros(nx)
         dynlib.dyn_jac(mid, _p(x), _p(u), _p(A), _p(B), _p(f))
-        assert np.allclose(f, g["ddyn"][i], rtol=1e-12, atol=1e-13)
-        assert np.allclose(A, g["A_fd"][i], rtol=1e-6, atol=1e-7)
-        assert np.allclose(B, g["B_fd"][i], rtol=1e-6, atol=1e-7)
+        assert np.allclose(f, g["ddyn"][i], rtol=1e-12, atol=1e-13 * _scale(g["ddyn"][i]))
+        assert np.allclose(A, g["A_fd"][i], rtol=1e-6, atol=1e-7 * _scale(g["A_fd"][i]))
+        assert np.allclose(B, g["B_fd"][i], rtol=1e-6, atol=1e-7 * _scale(g["B_fd"][i]))
+
+
+@pytest.mark.parametrize("fixture", FIXTURES)
+@pytest.mark.parametrize("name,mid", [("pendulum", 0), ("quadrotor", 1), ("rocket", 2)])
+def test_oracle_dynamics_vs_reference_values_and_vs_product_ad(dynlib, name, mid, fixture):
+    g = dict(np.load(os.path.join(GOLDEN, fixture.format(name))))
+    nx, nu = int(g["dims"][0]), int(g["dims"][1])
+    worst = 0.0
+    for i in range(g["X"].shape[0]):
+        x, u = np.ascontiguousarray(g["X"][i]), np.ascontiguousarray(g["U"][i])
+        assert np.allclose(DO.ode(mid, x, u), g["ode"][i], rtol=1e-12, atol=1e-12 * _scale(g["ode"][i]))
+        Ao, Bo, fo = DO.jac(mid, x, u)
+        assert np.allclose(fo, g["ddyn"][i], rtol=1e-12, atol=1e-13 * _scale(g["ddyn"][i]))
+        assert np.allclose(Ao, g["A_fd"][i], rtol=1e-6, atol=1e-7 * _scale(g["A_fd"][i]))
+        assert np.allclose(Bo, g["B_fd"][i], rtol=1e-6, atol=1e-7 * _scale(g["B_fd"][i]))
+        A, B, f = np.zeros((nx, nx)), np.zeros((nx, nu)), np.zeros(nx)
+        dynlib.dyn_jac(mid, _p(x), _p(u), _p(A), _p(B), _p(f))
+        worst = max(worst, np.max(np.abs(A - Ao)) / _scale(Ao), np.max(np.abs(B - Bo)) / _scale(Bo))
+    assert worst < 1e-10, worst

@@ -213,10 +213,12 @@ def test_linearize_vs_reference_dynamics(model):
     assert not np.allclose(A[1], A[0])
 
 
-@pytest.mark.parametrize("model,N,steps,amp", [("pendulum", 10, 4, 1.0), ("rocket", 20, 2, 0.3)])
+@pytest.mark.parametrize("model,N,steps,amp", [("pendulum", 10, 4, 1.0), ("rocket", 20, 2, 0.3), ("quadrotor", 20, 3, 1.0)])
 def test_closed_loop_vs_oracle(model, N, steps, amp):
     """Whole closed-loop MPC steps on the device (linearise -> fast-SLS -> nominal update -> warm-start shift -> plant + noise)
-    against the CPU restatement of SCP_SLS.solve / reset_warm_start built on the oracle; script settings (rti, rti_steps, weights, E)."""
+    against the CPU restatement of SCP_SLS.solve / reset_warm_start built on the oracle (its plant and Jacobians: oracle/dyn_oracle.py, numpy,
+    complex step -- not the product's dynamics.hpp); script settings (rti, rti_steps, weights, E): pendulum rti=3 / 2 fast-SLS steps
+    (main_pendulum...:49-58), quadrotor rti=3 / 2 (main_quadrotor...:62-69), rocket rti=1 / 1 (main_rocket...:80-85)."""
     from robust_nonlinear_mpc_amd import ClosedLoopMPC, get_model
     from problems import run_oracle_closed_loop
     m = get_model(model)
@@ -225,6 +227,10 @@ def test_closed_loop_vs_oracle(model, N, steps, amp):
     x0 = np.stack([m.x_ref + amp * 0.05 * (m.x_ub - m.x_lb) * rng.uniform(-1, 1, m.nx) for _ in range(B)])
     if model == "pendulum":
         x0[0] = m.extra["x0"]          # the script's initial state (main_pendulum...:60)
+    if model == "quadrotor":           # the script's recipe for its (unseeded) random initial state, seeded here (main_quadrotor...:82-90)
+        D = np.array([2.0] * 3 + [1.0] * 3 + [0.0] + [0.1] * 3 + [0.5] * 3)
+        x0 = m.x_ref + D * rng.uniform(-1, 1, (B, m.nx))
+        x0[:, 6:10] /= np.linalg.norm(x0[:, 6:10], axis=1, keepdims=True)
     W = rng.uniform(-1, 1, (steps, B, m.nx)) if model == "rocket" else None
     cl = ClosedLoopMPC(m, N, B)
     out = cl.run(x0, steps, W)
@@ -245,13 +251,19 @@ def test_closed_loop_vs_oracle(model, N, steps, amp):
         for i in range(steps):
             if ref["backoff_x"][i] is not None:
                 assert np.allclose(out["backoff_trajectory_x"][b][:, :, i].T, ref["backoff_x"][i], rtol=1e-5, atol=1e-8)
+        # primal_infeasibility of socp_step (SCP_SLS_jit.py:449-456): O(linearisation error^2), compared absolutely
+        ok = np.array(ref["success"], dtype=bool)
+        assert np.allclose(out["primal_infeasibility"][b][ok], np.array(ref["primal_infeasibility"])[ok], rtol=1e-4, atol=1e-9)
+        assert np.array_equal(out["primal_infeasibility"][b], dev["primal_infeasibility"][b], equal_nan=True)
+    assert (out["t_jac"] > 0).all() and (dev["t_jac"] > 0).all()      # the linearisation is timed on the device (the scripts' t_jac)
 
 
-@pytest.mark.parametrize("model,N,steps,sls_steps", [("pendulum", 10, 2, None), ("pendulum", 10, 2, 2), ("quadrotor", 20, 1, 1)])
+@pytest.mark.parametrize("model,N,steps,sls_steps", [("pendulum", 10, 2, None), ("pendulum", 10, 2, 2), ("quadrotor", 20, 1, 1), ("rocket", 20, 1, 1),
+                                                     ("rocket", 20, 1, None)])
 def test_closed_loop_scp_converge_mode_vs_oracle(model, N, steps, sls_steps):
     """SCP_SLS's default rti = -1 (BASELINE config 4, "full SCP_SLS_jit outer loop"): every instance iterates linearise -> fast-SLS ->
     nominal += delta until |delta|inf < epsilon_convergence, leaving the loop on its own (SCP_SLS_jit.py:113-135); inner fast-SLS in
-    converge mode (sls_steps None, MAX_ITER 30) or RTI.  epsilon_convergence is loosened from the reference's 1e-10 to 1e-8 on BOTH
+    converge mode (sls_steps None, MAX_ITER 30) or RTI.  The rocket cases are BASELINE config 4 itself (rockETH N=20, SCP outer loop).  epsilon_convergence is loosened from the reference's 1e-10 to 1e-8 on BOTH
     sides: the last digits of a QP solution are solver noise, and the test compares iteration counts."""
     from robust_nonlinear_mpc_amd import ClosedLoopMPC, get_model
     from problems import run_oracle_closed_loop
@@ -529,9 +541,48 @@ def test_script_rocket_x0_runs_closed_loop_from_the_gpu_initialiser():
         assert defect < 1e-6, defect
         assert (X[b, 1:] <= m.x_ub + 1e-8).all() and (X[b, 1:] >= m.x_lb - 1e-8).all()
         assert (U[b] <= m.u_ub + 1e-8).all() and (U[b] >= m.u_lb - 1e-8).all()
-    ok = [cl.step(W[i])["success"] for i in range(steps)]
+    # the closed loop from that nominal against the CPU restatement started from the SAME first nominal (the role IPOPT's has in the script):
+    # states, inputs and nominal trajectories to 1e-6, step by step, with the seeds' own disturbance streams
+    from problems import run_oracle_closed_loop
+    out = [cl.step(W[i]) for i in range(steps)]
     cl.close()
-    assert np.all(ok)
+    assert np.all([o["success"] for o in out])
+    for b in range(B):
+        ref = run_oracle_closed_loop(m, N, x0[b], steps, m.rti, m.fast_sls_rti_steps, W[:, b], X_nom=X[b], U_nom=U[b])
+        assert all(ref["success"])
+        scale = max(1.0, np.abs(ref["nominal_x"]).max())
+        for i in range(steps):
+            assert np.max(np.abs(out[i]["nominal_x"][b] - ref["nominal_x"][i])) < 1e-6 * scale, (b, i)
+            assert np.max(np.abs(out[i]["nominal_u"][b] - ref["nominal_u"][i])) < 1e-6 * max(1.0, np.abs(ref["nominal_u"]).max()), (b, i)
+            assert np.allclose(out[i]["backoff_x"][b], ref["backoff_x"][i], rtol=1e-5, atol=1e-8)
+
+
+def test_config5_shaped_monte_carlo_1024_seeds_30_steps():
+    """BASELINE config 5 at its per-GPU size: 1024 disturbance seeds x 30 closed-loop steps of the rocket (N = 20, script weights, rti = 1, one fast-SLS
+    step; x0 = the script's initial state scaled to 0.3 of its distance from hover so that the roll-out initialiser applies).  Properties at full size:
+    the rerun is bit-identical, seed 0 follows the reference script's own disturbance stream (tests/golden/rocket_noise_seed0.npz: np.random.seed(0),
+    w = 2 rand(17) - 1 per step, main_rocket...:30,180), every step of every run is either solved or flagged, solved steps stay inside the box."""
+    from robust_nonlinear_mpc_amd import disturbance_stream, get_model, run_monte_carlo
+    m = get_model("rocket")
+    S, steps, N = 1024, 30, 20
+    x0 = m.x_ref + 0.3 * (m.extra["x0"] - m.x_ref)
+    r1 = run_monte_carlo(m, N, np.arange(S), steps, x0, slices=3, solve_nominal=True)
+    r2 = run_monte_carlo(m, N, np.arange(S), steps, x0, slices=3, solve_nominal=True)
+    for k in ("state_trajectory", "input_trajectory", "nominal_trajectory_x", "backoff_trajectory_x", "success", "primal_infeasibility"):
+        assert np.array_equal(r1[k], r2[k], equal_nan=True), k
+    Wg = np.load(os.path.join(GOLDEN, "rocket_noise_seed0.npz"))["W"]
+    assert np.array_equal(disturbance_stream(0, steps, m.nx), Wg[:steps])
+    # seed 0's plant really saw that stream: x_{t+1} = ddyn(x_t, u_t) + E w_t with the independent numpy plant
+    from problems import host_ddyn
+    X, U = r1["state_trajectory"][0], r1["input_trajectory"][0]           # (nx, steps), (nu, steps-1)
+    for t in range(steps - 1):
+        assert np.allclose(X[:, t + 1], host_ddyn(m.model_id, X[:, t], U[:, t]) + m.E @ Wg[t], rtol=0, atol=1e-9)
+    succ = r1["success"]
+    assert succ.shape == (S, steps) and succ.mean() > 0.99, succ.mean()
+    assert np.isfinite(r1["state_trajectory"]).all()
+    nx_ok = r1["nominal_trajectory_x"].transpose(0, 3, 2, 1)[succ]           # (runs x steps solved, N+1, nx)
+    assert (nx_ok[:, 1:] <= m.x_ub + 1e-6).all() and (nx_ok[:, 1:] >= m.x_lb - 1e-6).all()
+    assert len({r1["state_trajectory"][s].tobytes() for s in range(0, S, 97)}) == len(range(0, S, 97))    # seeds differ
 
 
 def test_monte_carlo_seeds_and_npz_keys(tmp_path):

@@ -181,3 +181,88 @@ def test_disturbance_stream_matches_reference_seed0(golden_dir):
     from robust_nonlinear_mpc_amd import disturbance_stream
     W = np.load(os.path.join(golden_dir, "rocket_noise_seed0.npz"))["W"]
     assert np.array_equal(disturbance_stream(0, 30, 17), W)
+
+
+def _fake_run_slice(model, N, seeds, steps, x0, device, noise, solve_nominal, continuation=1):
+    """Stand-in for the GPU closed loop of one slice: trajectories that encode (seed, step) so the gather can be checked exactly."""
+    seeds = np.asarray(seeds)
+    S = len(seeds)
+    st = seeds[:, None, None] * 1000.0 + np.arange(model.nx)[None, :, None] * 10.0 + np.arange(steps)[None, None, :]
+    ut = -(seeds[:, None, None] * 1000.0 + np.arange(model.nu)[None, :, None] * 10.0 + np.arange(steps - 1)[None, None, :])
+    return dict(state_trajectory=st, input_trajectory=ut, success=np.ones((S, steps), dtype=bool),
+                t_qp=np.full((steps, 1), float(S)), t_riccati=np.zeros((steps, 1)), t_jac=np.zeros((steps, 1)))
+
+
+def _mc_gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from robust_nonlinear_mpc_amd import get_model, monte_carlo
+    monte_carlo._run_slice = _fake_run_slice                     # no GPU here: only the sharding / slicing / gather logic runs
+    m = get_model("pendulum")
+    seeds = np.arange(100, 111)                                   # 11 seeds over 2 ranks: uneven shards (6 + 5), 2 slices per rank
+    r = monte_carlo.run_monte_carlo(m, 10, seeds, 4, m.extra["x0"], rank=rank, world=world, slices=2)
+    q.put((rank, r["seeds"].copy(), r["state_trajectory"].copy(), r["state_trajectory_all"].copy(), r["input_trajectory_all"].copy(), r["t_qp"].copy()))
+    dist.destroy_process_group()
+
+
+def test_run_monte_carlo_gather_branch_world_size_2_gloo():
+    """run_monte_carlo(rank, world): contiguous seed shards, slices inside a rank, one all_gather of the trajectories to every rank
+    (BASELINE config 5's multi-GPU leg) -- driven on two gloo ranks with the GPU slice replaced by a stand-in."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_mc_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=180) for _ in ps], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    seeds = np.arange(100, 111)
+    want = _fake_run_slice(__import__("robust_nonlinear_mpc_amd").get_model("pendulum"), 10, seeds, 4, None, 0, True, False)
+    assert list(res[0][1]) == list(seeds[:6]) and list(res[1][1]) == list(seeds[6:])
+    for rank, mine, st, st_all, u_all, t_qp in res:
+        lo = 0 if rank == 0 else 6
+        assert np.array_equal(st, want["state_trajectory"][lo:lo + len(mine)])           # slices concatenated in seed order
+        assert np.array_equal(st_all, want["state_trajectory"])                            # every rank holds every seed's trajectory
+        assert np.array_equal(u_all, want["input_trajectory"])
+        assert t_qp.max() == 3.0                                                           # slices run concurrently: max over the 3 + 3 (or 2 + 3) split
+
+
+def test_bench_gpus_flag_launches_ranks_or_refuses(monkeypatch):
+    """`bench.py --gpus N` without a launcher starts N rank processes itself (torch.distributed.run, 127.0.0.1) before touching the GPU;
+    under a launcher with a different WORLD_SIZE it refuses instead of printing a line for the wrong N."""
+    import subprocess
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd: calls.append(cmd) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1", "--backend", "gloo"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(calls) == 1
+    cmd = calls[0]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "127.0.0.1" in cmd
+    assert cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:] == ["--gpus", "2", "--steps", "1", "--backend", "gloo"]
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 2 and len(calls) == 1
+
+
+def test_oracle_c_threaded_rti_batch_equals_the_python_driven_oracle():
+    """bench.py's cpu_baseline runs the oracle's RTI step from C threads (so_rti_step_batch); it must be the same computation as
+    OracleFastSLS.solve(rti_steps=1) driven from Python, instance by instance (bit-identical), for any thread count."""
+    from oracle import oracle as O
+    from problems import stack
+    insts = [make_instance("pendulum", s, 0.5) for s in range(5)]
+    m, d, N = insts[0].m, oracle_dims(insts[0]), insts[0].N
+    g = np.stack([np.stack(i.g_list[:N]) for i in insts])
+    gN = np.stack([i.g_list[N] for i in insts])
+    ref = [run_oracle_fastsls(i, rti_steps=1, settings=O.default_settings()) for i in insts]
+    for nt in (1, 3):
+        P, ok, done = O.rti_step_batch(d, stack(insts, "A"), stack(insts, "B"), g, gN, stack(insts, "c"), stack(insts, "q"), stack(insts, "x0_arg"), m.G, m.Gf, m.gf,
+                                       insts[0].E, m.Q, m.R, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, O.default_settings(), nthreads=nt)
+        assert done == 5 and ok.all()
+        for b in range(5):
+            assert np.array_equal(P[b], ref[b]["primal_vec"])

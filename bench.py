@@ -202,7 +202,12 @@ def qp_statistics(stats):
         cold = its > 0
         out[name] = {
             "solved_frac": float(solved.mean()), "certified_frac": float((st == 0).mean()),
-            "started_warm_frac": float(warm.mean()), "cold_fallback_frac": float(fb.mean()), "interior_point_frac": float(cold.mean()),
+            "started_warm_frac": float(warm.mean()), "interior_point_frac": float(cold.mean()),
+            # how the solve got to its answer: first active-set attempt (warm set, or the empty set on a cold solve) / interior point from scratch /
+            # interior point restarted from the first QP's iterate / active set from the empty set after a failed warm attempt
+            "path_frac": {"first_attempt": float((fb == 0).mean()), "ipm_cold": float((fb == 1).mean()), "ipm_restart": float((fb == 2).mean()),
+                          "empty_set_after_warm": float((fb == 3).mean())},
+            "cold_fallback_frac": float(((fb == 1) | (fb == 2)).mean()), "active_set_rounds_mean": float(rounds.mean()),
             "ipm_iters_mean": float(its[cold].mean()) if cold.any() else 0.0, "ipm_iters_p99": float(np.percentile(its[cold], 99)) if cold.any() else 0.0,
             "ipm_iters_max": int(its.max()), "block_solves_mean": float(blk.mean()), "block_solves_p99": float(np.percentile(blk, 99)), "block_solves_max": int(blk.max()),
             "factorisations_mean": float(fac.mean()),
@@ -253,7 +258,11 @@ def main():
     n_var = nz * N + m.nx
 
     def tune(f, synthetic=False):
-        f.opts.warm_rounds = int(os.environ.get('QP_WARM_ROUNDS', '4'))
+        if os.environ.get('QP_WARM_ROUNDS'):
+            f.opts.warm_rounds = int(os.environ['QP_WARM_ROUNDS'])
+        for k in ('as_first', 'as_rounds', 'as_max_viol', 'ipm_restart'):
+            if os.environ.get('QP_' + k.upper()):
+                setattr(f.opts, k, int(os.environ['QP_' + k.upper()]))
         f.opts.precision = args.precision
         f.opts.time_kernels = 1          # HIP events around every launch of the dominant kernel, on its own stream (roofline leg)
         if args.qp_eps is not None:

@@ -30,8 +30,8 @@ extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
     o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-6; o->conv_tol = 1e-3;
-    o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 4;
-    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0;
+    o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 6;
+    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0; o->as_first = 1; o->as_rounds = 8; o->as_max_viol = 64; o->ipm_restart = 1;
 }
 
 struct slsqp_handle {
@@ -50,6 +50,7 @@ struct slsqp_handle {
     int *scp_active, *scp_success, *scp_iters, *pending_reset, *scp_upd; double *scp_dmax;
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
     int *retry; int mx_retry, mx_retry_total;
+    double call_id;             // counts fast-SLS calls (validity of the interior-point iterate copies, QpArgs::call_id)
     int *qpstat;                // (B,2,8) per-QP statistics, see QpArgs::qpstat
     int *stale;                 // (B) bit 0: eta / eta_f, bit 1: K hold values from before the last slsqp_reset (zeroed lazily on slsqp_get)
     double *pinf; double t_jac;  // primal_infeasibility of the last SCP update (SCP_SLS_jit.py:449-456); linearisation time of the last cl_step
@@ -120,7 +121,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(h->owned, &h->u0, B * nu); rc |= dalloc(h->owned, &h->wbuf, B * nx); rc |= dalloc(h->owned, &h->u_init, (size_t)nu); h->cl_steps = 0; rc |= dalloc(h->owned, &h->cst, (size_t)(3 * nx + 2 * nu) * 2);
     rc |= dalloc(h->owned, &h->ubg, B * h->mb); rc |= dalloc(h->owned, &h->lbg, B * h->mb);
     rc |= dalloc(h->owned, &h->primal, B * h->n); rc |= dalloc(h->owned, &h->dual, B * h->mb); rc |= dalloc(h->owned, &h->cost, B); rc |= dalloc(h->owned, &h->pin_dual, B * nx);
-    rc |= dalloc(h->owned, &h->kkt, B * 8); rc |= dalloc(h->owned, &h->prev_primal, B * h->n); rc |= dalloc(h->owned, &h->Linv, B * N * nx * nx); rc |= dalloc(h->owned, &h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(h->owned, &h->qpstate, B * 20);
+    rc |= dalloc(h->owned, &h->kkt, B * 8); rc |= dalloc(h->owned, &h->prev_primal, B * h->n); rc |= dalloc(h->owned, &h->Linv, B * N * nx * nx); rc |= dalloc(h->owned, &h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(h->owned, &h->qpstate, B * 32);
     rc |= dalloc(h->owned, &h->eta, B * N * N * ni); rc |= dalloc(h->owned, &h->eta_f, B * (N + 1) * nif); rc |= dalloc(h->owned, &h->beta, B * N * N * ni);
     rc |= dalloc(h->owned, &h->beta_f, B * (N + 1) * nif); rc |= dalloc(h->owned, &h->backoff, B * N * ni); rc |= dalloc(h->owned, &h->backoff_f, B * nif);
     rc |= dalloc(h->owned, &h->backoff_x, B * (N + 1) * nx); rc |= dalloc(h->owned, &h->backoff_u, B * N * nu); rc |= dalloc(h->owned, &h->K, B * N * (N + 1) * nu * nx);
@@ -136,7 +137,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     if (rc) { free_all(h->owned); hipStreamDestroy(h->st); delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
     h->kev.resize(2 * 256); for (auto &e : h->kev) hipEventCreate(&e);
-    h->n_kev = 0; h->t_fwd = 0; h->n_fwd = 0; h->fwd_inst = 0; h->time_kernels = false;
+    h->n_kev = 0; h->t_fwd = 0; h->n_fwd = 0; h->fwd_inst = 0; h->time_kernels = false; h->call_id = 0;
     // CSC offsets of the reference's frozen pattern (qp_jit.py:101-123,178-186; columns sorted by row)
     {
         std::vector<int> mA((size_t)N * nx * nx), mB((size_t)N * nx * nu);
@@ -351,11 +352,23 @@ template <int NX, int NU>
 static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter, bool mx) {
     const size_t lds = mx ? QpLdsMx<NX, NU>::BYTES : sizeof(double) * qp_lds_doubles<NX, NU>(h->d.N);
     const dim3 grid(h->B), blk(64);
+    // every instance needs 1 (start) + 2 per interior-point iteration + (1 + n_refine) per polish round ticks, after at most warm_rounds + as_rounds
+    // active-set rounds of the attempts that precede the interior point
+    const int max_ticks = 1 + 2 * max_iter + 3 + 2 * 10 + 8 + 2 + 16 + 2 * (a.warm_rounds + a.as_rounds + 2);
+    static const bool persistent = getenv("SLSQP_PERSISTENT") ? atoi(getenv("SLSQP_PERSISTENT")) != 0 : true;
+    if (!mx && persistent) {
+        // one launch per QP solve: every wave runs its instance to completion (k_qp_solve)
+        const bool timed = h->time_kernels && h->n_kev + 2 <= (int)h->kev.size();
+        if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
+        hipLaunchKernelGGL((k_qp_solve<NX, NU>), grid, blk, lds, h->st, a, max_ticks);
+        if (timed) { hipEventRecord(h->kev[h->n_kev + 1], h->st); h->n_kev += 2; }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     HIPCHK(hipMemsetAsync(a.n_active, 0, sizeof(int), h->st));
     hipLaunchKernelGGL((k_phase<NX, NU>), grid, blk, 0, h->st, a, 1);
-    // every instance needs 1 (start) + 2 per interior-point iteration + (1 + n_refine) per polish round ticks; poll the number of
-    // unfinished instances every few ticks instead of running the worst case
-    const int max_ticks = 1 + 2 * max_iter + 3 + 2 * 10 + 8 + 2 + 16;
+    // tick kernels (mixed precision; fp64 with SLSQP_PERSISTENT=0): poll the number of unfinished instances every few ticks instead of
+    // running the worst case
     static const int first_burst = getenv("SLSQP_BURST0") ? atoi(getenv("SLSQP_BURST0")) : 12, tail_burst = getenv("SLSQP_BURST") ? atoi(getenv("SLSQP_BURST")) : 3;
     int tick = 0, active = 1;
     while (tick < max_ticks && active > 0) {
@@ -378,6 +391,12 @@ static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter, bool mx) 
     return 0;
 }
 
+// kernel events recorded by launches that did not wait for their kernels (k_qp_solve): read once the stream has been synchronised
+static void harvest_kernel_events(slsqp_handle *h) {
+    for (int i = 0; i + 1 < h->n_kev; i += 2) { float ms = 0; if (hipEventElapsedTime(&ms, h->kev[i], h->kev[i + 1]) == hipSuccess) { h->t_fwd += ms; h->n_fwd++; } }
+    h->n_kev = 0;
+}
+
 // instances of `run` whose mixed-precision solve did not end on the KKT certificate are solved again in fp64
 __global__ void k_mark_retry(int B, const int *run, const int *status, int *retry, int *count) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,9 +406,11 @@ __global__ void k_mark_retry(int B, const int *run, const int *status, int *retr
     if (r) atomicAdd(count, 1);
 }
 
-static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr, int stat_slot = 0) {
+static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr, int stat_slot = 0, int snap_take = 0, int snap_use = 0) {
     QpArgs a;
     a.qpstat = h->qpstat; a.stat_slot = stat_slot;
+    static const double snap_mu = getenv("SLSQP_SNAP_MU") ? atof(getenv("SLSQP_SNAP_MU")) : 1e-3;
+    a.snap_take = snap_take; a.snap_use = snap_use && o->ipm_restart; a.snap_mu = snap_mu; a.call_id = h->call_id; a.as_first = o->as_first; a.as_rounds = o->as_rounds; a.as_max_viol = o->as_max_viol;
     a.prox = prox; a.prox_stride = 12; a.inst_launches = h->inst_launches;
     a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;
     a.cst = costs_of(h); a.Linv = h->Linv; a.ws = h->ws; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
@@ -417,7 +438,7 @@ static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int w
         h->mx_retry = nretry; h->mx_retry_total += nretry;
         if (nretry > 0) {
             QpArgs r = a;
-            r.run = h->retry; r.warm = 0; r.n_refine = 1; r.early_ctol = 1e-6;
+            r.run = h->retry; r.warm = 0; r.n_refine = 1; r.early_ctol = 1e-6; r.snap_take = 0; r.snap_use = 0;
             if (go(r, false)) return -1;
         }
     }
@@ -461,6 +482,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     }
     const bool rti = o.rti_steps > 0;
     const int steps = rti ? o.rti_steps : o.max_sls_iter;
+    h->call_id += 1.0;
     std::vector<float> tq, ts;
     HIPCHK(hipEventRecord(h->ev[0], h->st));
     if (active) hipLaunchKernelGGL(k_copy_int, dim3(gb), dim3(256), 0, h->st, active, h->alive, B);
@@ -476,7 +498,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     double acc_qp = 0, acc_sw = 0;
     for (int i = 0; i < steps; i++) {
         HIPCHK(hipEventRecord(h->ev[1], h->st));
-        if (launch_qp(h, h->alive, &o, (i > 0 || o.warm_start) ? 1 : 0)) return -1;
+        if (launch_qp(h, h->alive, &o, (i > 0 || o.warm_start) ? 1 : 0, nullptr, 0, 1, i > 0 ? 1 : 0)) return -1;
         HIPCHK(hipEventRecord(h->ev[2], h->st));
         hipLaunchKernelGGL(k_post_qp, dim3(gb), dim3(256), 0, h->st, B, h->status, h->alive, h->infeas);
         EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff, h->stale};
@@ -493,16 +515,18 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         int nmask = 0;
         HIPCHK(hipMemcpyAsync(&nmask, h->counter, sizeof(int), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
+        harvest_kernel_events(h);
         acc_qp += ev_ms(h->ev[1], h->ev[2]); acc_sw += ev_ms(h->ev[3], h->ev[4]);
         if (!rti && nmask == 0) break;   // every instance converged or failed
     }
     // final QP: RTI always (fast_SLS_jit.py:293); converge mode only for instances that hit MAX_ITER (:311)
     HIPCHK(hipEventRecord(h->ev[1], h->st));
-    if (launch_qp(h, h->alive, &o, 1, nullptr, 1)) return -1;
+    if (launch_qp(h, h->alive, &o, 1, nullptr, 1, 1, 1)) return -1;
     HIPCHK(hipEventRecord(h->ev[2], h->st));
     hipLaunchKernelGGL(k_finish, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->alive, h->infeas, h->success, active, h->pending_reset);
     HIPCHK(hipEventRecord(h->ev[5], h->st));
     HIPCHK(hipStreamSynchronize(h->st));
+    harvest_kernel_events(h);
     acc_qp += ev_ms(h->ev[1], h->ev[2]);
     h->t_total = ev_ms(h->ev[0], h->ev[5]); h->t_qp = acc_qp; h->t_sweep = acc_sw;
     return 0;
@@ -693,6 +717,7 @@ extern "C" int slsqp_nominal_solve(slsqp_handle *h, int max_qp, double tol, doub
         int nact = 0;
         HIPCHK(hipMemcpyAsync(&nact, h->counter + 2, sizeof(int), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
+        harvest_kernel_events(h);
         tq += ev_ms(h->ev[6], h->ev[7]);
         if (nact == 0) break;
     }
@@ -857,6 +882,7 @@ extern "C" int slsqp_qp_solve(slsqp_handle *h, double *x, double *y, int *status
     if (launch_qp(h, nullptr, &o, o.warm_start ? 1 : 0)) return -1;
     HIPCHK(hipEventRecord(h->ev[1], h->st));
     HIPCHK(hipStreamSynchronize(h->st));
+    harvest_kernel_events(h);
     h->t_total = h->t_qp = ev_ms(h->ev[0], h->ev[1]); h->t_sweep = 0;
     const hipMemcpyKind kd = loc == SLSQP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     if (x) HIPCHK(hipMemcpyAsync(x, h->primal, sizeof(double) * (size_t)h->B * h->n, kd, h->st));

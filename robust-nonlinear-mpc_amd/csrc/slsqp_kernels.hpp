@@ -62,7 +62,7 @@ struct QpArgs {
     Costs cst;
     double *Linv;             // scratch (B,N,NX,NX)
     double *ws;               // scratch (B, qp_ws_doubles(n,N,NX)): the IPM's n-vectors
-    double *state;            // scratch (B,16): QpState
+    double *state;            // scratch (B,32): QpState
     int *n_active;            // number of instances still iterating
     double *primal;           // (B,n)
     double *dual;             // (B,mb)
@@ -81,6 +81,13 @@ struct QpArgs {
     unsigned long long *inst_launches;   // [0] += 1 per instance forward sweep, [1] += 1 per factorising one (roofline accounting of bench.py)
     int *qpstat;              // (B,2,8) or NULL: per instance and slot [its, block solves, factorising ones, active inequality rows, started warm,
     int stat_slot;            //   active-set correction rounds, status, fell back to the interior point]; slot = 0 first QP of a fast-SLS call, 1 its last QP
+    int snap_take;            // 1: keep a copy of this solve's interior-point iterate once mu <= snap_mu * max(1,|q|inf) (start for the next QP of the call)
+    int snap_use;             // 1: an instance whose warm active-set attempt fails restarts its interior point from that copy (same A, B, q; other bounds)
+    double snap_mu;
+    double call_id;           // identifies the fast-SLS call (a copy is only valid within the call that took it: same A, B, q)
+    int as_first;             // 1: a cold solve first tries the active-set iteration from the empty set (the equality-constrained optimum of P_INIT)
+    int as_rounds;            // rounds such an attempt may take (a warm one: warm_rounds)
+    int as_max_viol;          // an attempt is abandoned when a solve leaves more violated bounds than this, or more than 2 x the previous round's + 8
     int n_refine;             // refinement solves per polish (1 in fp64, 3 with fp32 factorisations)
     double early_ctol;        // tolerance (relative to max(1,|q|inf)) of the look at the un-refined polish solve: its accuracy class
 };
@@ -97,8 +104,9 @@ struct QpLds {
 template <int NX, int NU>
 __host__ __device__ constexpr int qp_lds_doubles(int) { return QpLds<NX, NU>::TOTAL; }
 
-// workspace arrays per instance (doubles): 12 n-vectors + 3 (N*NX)-vectors
-__host__ __device__ inline size_t qp_ws_doubles(int n, int N, int NX) { return (size_t)12 * n + (size_t)3 * N * NX; }
+// workspace arrays per instance (doubles): 12 n-vectors + 3 (N*NX)-vectors of the solver, then the copy of an interior-point iterate
+// (6 n-vectors + 1 (N*NX)-vector: z, s_u, s_l, lambda_u, lambda_l, E'nu, nu)
+__host__ __device__ inline size_t qp_ws_doubles(int n, int N, int NX) { return (size_t)18 * n + (size_t)4 * N * NX; }
 
 template <int NX, int NU>
 struct NeG {   // global-memory operands of the sweeps (this instance)
@@ -473,8 +481,13 @@ __device__ __forceinline__ Elem elem_of(int e, int n, int N, const double *ub, c
 // finished instances exit at once.  Splitting the former single kernel removed 340 VGPR + 382 SGPR spills.
 // ------------------------------------------------------------------------------------------------
 enum { P_INIT = 0, P_PRED = 1, P_CORR = 2, P_POL0 = 3, P_POL1 = 4, P_POL2 = 5, P_DONE = 6 };
-struct QpState {   // per instance, 20 doubles
+struct QpState {   // per instance, 32 doubles
     double phase, it, status, mu, smu, qscale, mtot, pol_round, pol_fail, warm, kst, kbox, ksign, pst, pbox, psign, ticks, fticks, tight, pad;
+    double snap_call, snap_mu, snap_used, pad2;   // call that took the iterate copy (0 = none), its mu, 1 = this solve restarted from it
+    double mode, cold_as, nviol, path;            // mode 1: P_INIT starts the interior point (0: an active-set attempt from the empty set);
+                                                  // cold_as 1: that attempt was made; nviol: violated bounds seen by the previous round;
+                                                  // path: how the solve ended up where it is (qp_stats[7])
+    unsigned long long seth[4];                   // hashes of the last active sets of the current attempt (a repeat = the iteration cycles)
 };
 
 template <int NX, int NU>
@@ -522,9 +535,25 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
     double *ws = a.ws + (size_t)b * qp_ws_doubles(n, N, NX);
     double *Z = ws, *SU = Z + n, *SL = SU + n, *LU = SL + n, *LL = LU + n, *GC = LL + n, *CU = GC + n, *CL = CU + n;
     double *PI = CL + n, *V = PI + n, *G = V + n, *ACT = G + n, *W = ACT + n, *NUA = W + N * NX, *NUP = NUA + N * NX;
+    double *SZ = NUP + N * NX, *SSU = SZ + n, *SSL = SSU + n, *SLU = SSL + n, *SLL = SLU + n, *SGC = SLL + n, *SNUA = SGC + n;   // copy of an interior-point iterate
     Costs cst = a.cst;
     cst.prox = a.prox ? a.prox[(size_t)b * a.prox_stride] : 0.0;
     QpState *stp = (QpState *)a.state + b;
+    // Restart of the interior point from the copy taken by an earlier QP of the same fast-SLS call (same A, B, q; the bounds moved): primal and
+    // multipliers are kept, a slack that the new bound would make smaller than min(s, max(sqrt(mu), 1e-3)) is pushed back to that floor.  On the
+    // closed-loop rocket QPs the tightened QP then needs 3-5 iterations instead of 6-7 (scripts/proto/ipm_warm_stats.py).
+    auto restore_iterate = [&](double mu_snap) {
+        const double smin = fmax(sqrt(fmax(mu_snap, 0.0)), 1e-3);
+#pragma unroll 4
+        for (int e = lane; e < n; e += 64) {
+            const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+            const double z = (e < NX) ? a.x0val[(size_t)b * NX + e] : SZ[e], su = SSU[e], sl = SSL[e];
+            Z[e] = z; GC[e] = SGC[e];
+            SU[e] = el.fu ? fmax(el.hi - z, fmin(su, smin)) : 1.0; LU[e] = el.fu ? SLU[e] : 0.0;
+            SL[e] = el.fl ? fmax(z - el.lo, fmin(sl, smin)) : 1.0; LL[e] = el.fl ? SLL[e] : 0.0;
+        }
+        for (int o = lane; o < N * NX; o += 64) NUA[o] = SNUA[o];
+    };
 
     if (first) {
         int status = ST_INIT;
@@ -562,6 +591,9 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             QpState s0;
             s0.phase = (status == ST_INIT) ? (warm ? P_POL0 : P_INIT) : P_DONE; s0.it = 0; s0.status = status; s0.mu = 0; s0.smu = 0; s0.qscale = qscale;
             s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1; s0.ticks = 0; s0.fticks = 0; s0.tight = 0; s0.pad = 0;
+            s0.snap_call = stp->snap_call; s0.snap_mu = stp->snap_mu; s0.snap_used = 0; s0.pad2 = 0;
+            s0.mode = a.as_first ? 0.0 : 1.0; s0.cold_as = 0; s0.nviol = 0; s0.path = warm ? 10.0 : 0.0;
+            s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
             if (status == ST_INIT) atomicAdd(a.n_active, 1);
@@ -575,8 +607,24 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
     int status = (int)s.status, it = (int)s.it;
     const double qscale = s.qscale, mtot = s.mtot, ptol = 1e-9 * qscale;
     double tol = (s.tight != 0.0 ? fmin(a.eps, 1e-9) : a.eps) * qscale;
-    bool polished = false, start_iter = false;
+    bool polished = false, start_iter = false, fall_back = false;
 
+    bool as_from_init = false;
+    if (phase == P_INIT && s.mode == 0.0) {
+        // active-set attempt from the empty set: the solve just made is its round 0 (all bounds inactive); hand it to the polish logic below
+#pragma unroll 4
+        for (int e = lane; e < n; e += 64) {
+            const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+            const double gc = G[e];
+            CU[e] = el.fr ? -(el.q + gc) * wla::fast_rcp(el.pd) : Z[e];
+            CL[e] = gc; ACT[e] = 0.0;
+        }
+        for (int o = lane; o < N * NX; o += 64) NUP[o] = W[o];
+        s.cold_as = 1.0; s.warm = 2.0; s.pol_round = 0.0; s.pol_fail = 0.0; s.nviol = 0.0;
+        as_from_init = true;
+        phase = P_POL0;
+        wla::wsync_mem();
+    }
     if (phase == P_INIT) {
         for (int o = lane; o < N * NX; o += 64) NUA[o] = W[o];
 #pragma unroll 4
@@ -676,50 +724,112 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
     } else {
         // polish phases: zn = v - Pi g  (v was z0 - Pi r or zn - Pi r1); CU := zn, CL := accumulated E' nu
         const bool firstp = (phase == P_POL0);
+        if (!as_from_init) {
 #pragma unroll 4
-        for (int e = lane; e < n; e += 64) {
-            const double gg = G[e];
-            CU[e] = V[e] - PI[e] * gg;
-            CL[e] = (firstp ? 0.0 : CL[e]) + gg;
+            for (int e = lane; e < n; e += 64) {
+                const double gg = G[e];
+                CU[e] = V[e] - PI[e] * gg;
+                CL[e] = (firstp ? 0.0 : CL[e]) + gg;
+            }
+            for (int o = lane; o < N * NX; o += 64) NUP[o] = (firstp ? 0.0 : NUP[o]) + W[o];
+            wla::wsync_mem();
         }
-        for (int o = lane; o < N * NX; o += 64) NUP[o] = (firstp ? 0.0 : NUP[o]) + W[o];
-        wla::wsync_mem();
-        const double max_rounds = (s.warm > 0.0) ? (double)a.warm_rounds : 8.0;
-        bool again = false;
-        if (phase == P_POL0 && s.pol_fail == 0.0 && s.pol_round < max_rounds) {
-            // cheap look at the un-refined solve: if the active set is visibly wrong (coarse tolerance) correct it now and
-            // factorise again, without spending the two refinement solves on a set that is about to change
-            const double ctol = a.early_ctol * qscale;
-            int changed = 0;
-    #pragma unroll 4
-        for (int e = lane; e < n; e += 64) {
+        const double max_rounds = (s.warm == 1.0) ? (double)a.warm_rounds : (s.warm == 2.0 ? (double)a.as_rounds : 8.0);
+        // Correction of the active set from the solve in CU (primal) / CL (E'nu): multipliers of the wrong sign leave, violated bounds enter --
+        // all of them for the inputs (control constraints are active on arcs), but for a state component only the stages where its violation
+        // has a local maximum along the horizon: state constraints are active at isolated touch points, and fixing a whole violated arc at once
+        // over-constrains the next solve and sets the iteration oscillating (measured on closed-loop rocket QPs: every warm attempt failed with
+        // the add-all rule, 3-5 rounds suffice with this one, scripts/proto/as_localmax.py).  Pass 1 writes the new set into G (free until the
+        // next backward sweep) because the rule reads neighbouring elements; pass 2 applies it.  Returns changes made; nv = violated bounds seen.
+        auto viol_at = [&](int e, double tolv) -> double {
+            if (e < NX || e >= n || ACT[e] != 0.0) return 0.0;
+            const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+            const double zn = CU[e];
+            double v = 0.0;
+            if (el.fu) v = fmax(v, zn - el.hi);
+            if (el.fl) v = fmax(v, el.lo - zn);
+            return v > tolv ? v : 0.0;
+        };
+        auto plan_set = [&](double tolv, double &nv, unsigned long long &hash) -> double {
+            // inputs first: a state that leaves its box because the input driving it does (actuator lags: servo angle / servo command) must not
+            // be pinned while that input is still free -- the next solve would swing the inputs by orders of magnitude.  Bounds on states enter
+            // only in rounds that find no violated input bound.
+            int in_viol = 0;
+            for (int o = lane; o < N * NU; o += 64) {
+                const int e = (o / NU) * NZ + NX + (o % NU);
+                in_viol |= (viol_at(e, tolv) > 0.0) ? 1 : 0;
+            }
+            const bool any_in = wla::wave_or(in_viol) != 0;
+            double changed = 0.0, viols = 0.0;
+            unsigned long long hv = 0ULL;
+#pragma unroll 2
+            for (int e = lane; e < n; e += 64) {
                 const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
                 const double zn = CU[e], gr = el.pd * zn + el.q + CL[e], ac = ACT[e];
-                if ((ac > 0.0 && gr > ctol) || (ac < 0.0 && -gr > ctol)) changed = 1;
-                if (ac == 0.0 && ((el.fu && zn > el.hi + ctol) || (el.fl && zn < el.lo - ctol))) changed = 1;
-            }
-            again = wla::wave_or(changed) != 0;
-            if (again) {
-                s.pol_round += 1.0;
-        #pragma unroll 4
-        for (int e = lane; e < n; e += 64) {
-                    const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                    const double zn = CU[e], gr = el.pd * zn + el.q + CL[e];
-                    double ac = ACT[e];
-                    if (ac > 0.0 && gr > ctol) ac = 0.0;
-                    if (ac < 0.0 && -gr > ctol) ac = 0.0;
-                    if (ac == 0.0) {
-                        if (el.fu && zn > el.hi + ctol) ac = 1.0;
-                        else if (el.fl && zn < el.lo - ctol) ac = -1.0;
+                double nac = ac;
+                if (ac > 0.0 && gr > tolv) nac = 0.0;
+                if (ac < 0.0 && -gr > tolv) nac = 0.0;
+                if (ac == 0.0 && el.fr) {
+                    const double vu = el.fu ? zn - el.hi : 0.0, vl = el.fl ? el.lo - zn : 0.0, v = fmax(vu, vl);
+                    if (v > tolv) {
+                        viols += 1.0;
+                        bool take = true;
+                        if ((e % NZ) < NX) take = !any_in && (v >= viol_at(e - NZ, tolv)) && (v >= viol_at(e + NZ, tolv));
+                        if (take) nac = vu > vl ? 1.0 : -1.0;
                     }
-                    const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zn);
-                    const double pi = (el.fr && ac == 0.0) ? wla::fast_rcp(el.pd) : 0.0;
-                    ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
                 }
+                if (nac != ac) changed += 1.0;
+                if (nac != 0.0) {   // splitmix64 of (element, side)
+                    unsigned long long x = (unsigned long long)(2 * e + (nac > 0.0 ? 1 : 0)) + 0x9E3779B97F4A7C15ULL;
+                    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; hv ^= x ^ (x >> 31);
+                }
+                G[e] = nac;
             }
-        }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned lo32 = __shfl_xor((unsigned)(hv & 0xFFFFFFFFULL), o), hi32 = __shfl_xor((unsigned)(hv >> 32), o);
+                hv ^= ((unsigned long long)hi32 << 32) | lo32;
+            }
+            hash = hv | 1ULL;      // never 0 (0 = empty slot)
+            nv = wla::wave_sum(viols);
+            return wla::wave_sum(changed);
+        };
+        // a set this attempt has already solved with: the iteration cycles
+        auto seen_before = [&](unsigned long long hsh) -> bool {
+            const bool rep = (hsh == s.seth[0]) || (hsh == s.seth[1]) || (hsh == s.seth[2]) || (hsh == s.seth[3]);
+            s.seth[3] = s.seth[2]; s.seth[2] = s.seth[1]; s.seth[1] = s.seth[0]; s.seth[0] = hsh;
+            return rep;
+        };
+        auto apply_set = [&]() {
+            wla::wsync_mem();
+#pragma unroll 4
+            for (int e = lane; e < n; e += 64) {
+                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                const double zn = CU[e], ac = G[e];
+                const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zn);
+                const double pi = (el.fr && ac == 0.0) ? wla::fast_rcp(el.pd) : 0.0;
+                ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
+            }
+        };
+        bool again = false, give_up = false;
+        if (phase == P_POL0 && s.pol_fail == 0.0 && s.pol_round < max_rounds) {
+            // cheap look at the un-refined solve: if the active set is visibly wrong (coarse tolerance) correct it now and
+            // factorise again, without spending the refinement solve on a set that is about to change
+            double nv = 0.0;
+            unsigned long long hsh = 0ULL;
+            const double changed = plan_set(a.early_ctol * qscale, nv, hsh);
+            again = changed > 0.0;
+            if (again && s.warm > 0.0 && seen_before(hsh)) { again = false; give_up = true; }
+            // an attempt (warm or from the empty set) whose solve blows up -- a set that pins both ends of a dynamics row leaves hundreds of
+            // violated bounds -- is left to the interior point at once
+            if (s.warm > 0.0 && (nv > (double)a.as_max_viol || (s.pol_round > 0.0 && nv > 2.0 * s.nviol + 8.0))) { again = false; give_up = true; }
+            s.nviol = nv;
+            if (again) { s.pol_round += 1.0; apply_set(); }
+        } else if (phase == P_POL0 && s.warm > 0.0) give_up = true;      // out of rounds (or a pivot failed): do not refine a set known to be wrong
         if (again) {
             phase = P_POL0;
+        } else if (give_up) {
+            fall_back = true;
         } else if (phase != P_POL2) {
     #pragma unroll 4
         for (int e = lane; e < n; e += 64) {
@@ -752,42 +862,46 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 polished = true; status = 0; s.kst = vst; s.kbox = vbox; s.ksign = vsign;
                 phase = P_DONE;
             } else if (!pf && vst < ptol && s.pol_round < max_rounds) {
-                // primal-dual active-set correction: release constraints whose multiplier has the wrong sign,
-                // add violated bounds, factorise again
-                s.pol_round += 1.0;
-        #pragma unroll 4
-        for (int e = lane; e < n; e += 64) {
-                    const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                    const double zn = CU[e], gr = el.pd * zn + el.q + CL[e];
-                    double ac = ACT[e];
-                    if (ac > 0.0 && gr > ptol) ac = 0.0;
-                    if (ac < 0.0 && -gr > ptol) ac = 0.0;
-                    if (ac == 0.0) {
-                        if (el.fu && zn > el.hi + ptol) ac = 1.0;
-                        else if (el.fl && zn < el.lo - ptol) ac = -1.0;
-                    }
-                    const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zn);
-                    const double pi = (el.fr && ac == 0.0) ? wla::fast_rcp(el.pd) : 0.0;
-                    ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
-                }
-                phase = P_POL0;
+                // primal-dual active-set correction on the refined solve (tight tolerance), factorise again
+                double nv = 0.0;
+                unsigned long long hsh = 0ULL;
+                plan_set(ptol, nv, hsh);
+                if (s.warm > 0.0 && seen_before(hsh)) fall_back = true;
+                else { s.pol_round += 1.0; s.nviol = nv; apply_set(); phase = P_POL0; }
             } else if (s.warm > 0.0) {
-                // warm attempt failed: cold start of the interior point (rhs of P_INIT)
-                s.warm = -1.0; s.pol_round = 0.0; s.pol_fail = 0.0;      // -1: warm attempt abandoned
-        #pragma unroll 4
-        for (int e = lane; e < n; e += 64) {
-                    const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
-                    const double z0 = (e < NX) ? a.x0val[(size_t)b * NX + e] : 0.0;
-                    const double pi = el.fr ? wla::fast_rcp(el.pd) : 0.0;
-                    PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q); Z[e] = z0;
-                }
-                phase = P_INIT;
+                fall_back = true;      // warm / cold active-set attempt failed
             } else if (s.tight == 0.0 && a.eps > 1e-9 && status == 4) {
                 // the interior point stopped at a loose tolerance and its active-set guess did not certify: resume it (its state
                 // arrays are untouched by the polish) down to 1e-9, then polish again
                 s.tight = 1.0; s.pol_round = 0.0; s.pol_fail = 0.0; tol = fmin(a.eps, 1e-9) * qscale;
                 start_iter = true;
             } else phase = P_DONE;
+        }
+    }
+
+    if (fall_back) {
+        // an active-set attempt is abandoned.  A warm one is followed by the attempt from the empty set (when enabled and not yet made), then
+        // the interior point takes over: from the iterate an earlier QP of this call left behind when there is one (no P_INIT solve then),
+        // from its cold start otherwise
+        const bool try_cold_as = a.as_first && s.cold_as == 0.0 && s.warm == 1.0;
+        s.pol_round = 0.0; s.pol_fail = 0.0; s.seth[0] = s.seth[1] = s.seth[2] = s.seth[3] = 0ULL;
+        if (!try_cold_as && a.snap_use && s.snap_call == a.call_id && a.call_id != 0.0) {
+            s.warm = -1.0; s.path = (s.path >= 10.0 ? 10.0 : 0.0) + 2.0;
+            restore_iterate(s.snap_mu);
+            s.snap_used = 1.0;
+            start_iter = true;
+        } else {
+            const double w10 = s.path >= 10.0 ? 10.0 : 0.0;
+            if (try_cold_as) { s.mode = 0.0; s.path = w10 + 3.0; s.warm = -1.0; }
+            else { s.mode = 1.0; s.path = w10 + 1.0; s.warm = -1.0; }
+    #pragma unroll 4
+            for (int e = lane; e < n; e += 64) {
+                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                const double z0 = (e < NX) ? a.x0val[(size_t)b * NX + e] : 0.0;
+                const double pi = el.fr ? wla::fast_rcp(el.pd) : 0.0;
+                PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q); Z[e] = z0;
+            }
+            phase = P_INIT;
         }
     }
 
@@ -811,6 +925,13 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         const double res = wla::wave_max(rmax);
         const double mu = wla::wave_sum(musum) / mtot;
         s.mu = mu; s.kst = res;
+        // first iterate of this solve with mu below snap_mu |q|inf (but not already at the end of the path): keep a copy for the next QP of the call
+        if (a.snap_take && s.pad2 == 0.0 && mu <= a.snap_mu * qscale && mu >= 1e-2 * a.snap_mu * qscale && res == res) {
+#pragma unroll 4
+            for (int e = lane; e < n; e += 64) { SZ[e] = Z[e]; SSU[e] = SU[e]; SSL[e] = SL[e]; SLU[e] = LU[e]; SLL[e] = LL[e]; SGC[e] = GC[e]; }
+            for (int o = lane; o < N * NX; o += 64) SNUA[o] = NUA[o];
+            s.pad2 = 1.0; s.snap_call = a.call_id; s.snap_mu = mu;
+        }
         if (!(res == res) || !(mu == mu) || res > 1e30) { status = 3; phase = P_DONE; }
         else if (res < tol && mu < tol) {
             status = 4;
@@ -863,8 +984,8 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         if (lane == 0) {
             if (a.qpstat) {
                 int *qs = a.qpstat + ((size_t)b * 2 + a.stat_slot) * 8;
-                qs[0] = it; qs[1] = (int)stp->ticks; qs[2] = (int)stp->fticks; qs[3] = (int)nact; qs[4] = (s.warm != 0.0) ? 1 : 0;
-                qs[5] = (int)s.pol_round; qs[6] = status; qs[7] = (s.warm < 0.0) ? 1 : 0;
+                qs[0] = it; qs[1] = (int)stp->ticks; qs[2] = (int)stp->fticks; qs[3] = (int)nact; qs[4] = (int)s.path / 10;
+                qs[5] = (int)s.pol_round; qs[6] = status; qs[7] = (int)s.path % 10;   // 0: first attempt succeeded (warm set, or empty set on a cold solve); 1: cold interior point; 2: interior point restarted from an iterate copy; 3: active set from the empty set after a failed warm attempt
             }
             if (ok) a.cost[b] = csum;
             a.status[b] = status;
@@ -909,6 +1030,53 @@ __global__ __launch_bounds__(64) void k_ne_bwd_phase(QpArgs a) {
     wla::wsync_mem();
     phase_update<NX, NU>(a, 0, b, lane);
 #endif
+}
+
+// The whole QP solve of one instance in one launch: the wave loops over its ticks (forward sweep, backward sweep, phase logic) until its
+// instance is done, so instances advance independently -- no launch per tick, no host poll, no batch-wide barrier between ticks; the
+// hardware's workgroup dispatcher fills the slots that finished instances free.  Same device functions, same arithmetic, same results as the
+// tick kernels (k_phase / k_ne_fwd / k_ne_bwd_phase), which remain for the mixed-precision path.
+#ifndef QP_PERSIST_WAVES_PER_SIMD
+#define QP_PERSIST_WAVES_PER_SIMD 3
+#endif
+template <int NX, int NU>
+__global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpArgs a, int max_ticks) {
+    int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B || (a.run && !a.run[b])) return;
+    extern __shared__ double sm[];
+    phase_update<NX, NU>(a, 1, b, lane);
+    wla::wsync_mem();
+    unsigned long long n_sweeps = 0, n_factor = 0;
+    for (int t = 0; t < max_ticks; t++) {
+        // The instance index and the lane id are laundered through empty asm statements at the head of every part: nothing computed from them
+        // is loop-invariant for the compiler then, so it cannot hoist the phase logic's per-element loads (bounds, weights, linear cost) out of
+        // the tick loop and keep them in registers across the sweeps (256 VGPRs + 118 spilled when it does; 168-194 like this).
+        asm volatile("" : "+s"(b));
+        asm volatile("" : "+v"(lane));
+        QpState *st = (QpState *)a.state + b;
+        const int phase = (int)st->phase;
+        if (phase == P_DONE) break;
+        const bool factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
+        const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
+        double bmax = 0.0;
+        const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane, nullptr, &bmax);
+        if (lane == 0) {
+            if (phase == P_POL1 || phase == P_POL2) st->pbox = bmax;
+            st->ticks += 1.0;
+            if (factor) { st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; }
+        }
+        n_sweeps++; n_factor += factor ? 1 : 0;
+        wla::wsync_mem();
+        asm volatile("" : "+s"(b));
+        asm volatile("" : "+v"(lane));
+        ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
+        wla::wsync_mem();
+        asm volatile("" : "+s"(b));
+        asm volatile("" : "+v"(lane));
+        phase_update<NX, NU>(a, 0, b, lane);
+        wla::wsync_mem();
+    }
+    if (lane == 0 && n_sweeps) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); }
 }
 
 #ifndef QP_MX_WAVES_PER_SIMD

@@ -432,6 +432,7 @@ def test_sliced_batch_is_bitwise_the_single_slice_result():
         f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=nb)
         f.set_rti_steps(1)
         f.opts.warm_start = 0
+        f.opts.time_kernels = 1          # per-launch HIP events are opt-in (bench.py's roofline leg)
         return f
 
     res = {}

@@ -201,7 +201,12 @@ class OracleQP:
     def solve(self, x0):
         d = self.d
         l, u = self.bounds_with_x0(x0)
-        x, y, info = qp_solve(d, self.A, self.B, self.G, self.Gf, self.Q, self.R, self.Qf, self.q, l, u, self.settings)
+        if getattr(self, "backend", None) is not None:
+            # alternative exact solver supplied by the tests (dense interior point, tests/problems.py:ipm_backend) for QPs on which the ADMM
+            # restatement does not reach eps 1e-9 within its iteration cap; same data, same row layout, same packing
+            x, y, info = self.backend(self, l, u)
+        else:
+            x, y, info = qp_solve(d, self.A, self.B, self.G, self.Gf, self.Q, self.R, self.Qf, self.q, l, u, self.settings)
         self.last_info = info
         if info.status not in (1, 2):  # qp_jit.py:397
             return {"success": False, "status": info.status}

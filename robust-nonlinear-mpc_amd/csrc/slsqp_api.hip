@@ -121,7 +121,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(h->owned, &h->u0, B * nu); rc |= dalloc(h->owned, &h->wbuf, B * nx); rc |= dalloc(h->owned, &h->u_init, (size_t)nu); h->cl_steps = 0; rc |= dalloc(h->owned, &h->cst, (size_t)(3 * nx + 2 * nu) * 2);
     rc |= dalloc(h->owned, &h->ubg, B * h->mb); rc |= dalloc(h->owned, &h->lbg, B * h->mb);
     rc |= dalloc(h->owned, &h->primal, B * h->n); rc |= dalloc(h->owned, &h->dual, B * h->mb); rc |= dalloc(h->owned, &h->cost, B); rc |= dalloc(h->owned, &h->pin_dual, B * nx);
-    rc |= dalloc(h->owned, &h->kkt, B * 8); rc |= dalloc(h->owned, &h->prev_primal, B * h->n); rc |= dalloc(h->owned, &h->Linv, B * N * nx * nx); rc |= dalloc(h->owned, &h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(h->owned, &h->qpstate, B * 32);
+    rc |= dalloc(h->owned, &h->kkt, B * 8); rc |= dalloc(h->owned, &h->prev_primal, B * h->n); rc |= dalloc(h->owned, &h->Linv, B * N * nx * nx); rc |= dalloc(h->owned, &h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(h->owned, &h->qpstate, B * 36);
     rc |= dalloc(h->owned, &h->eta, B * N * N * ni); rc |= dalloc(h->owned, &h->eta_f, B * (N + 1) * nif); rc |= dalloc(h->owned, &h->beta, B * N * N * ni);
     rc |= dalloc(h->owned, &h->beta_f, B * (N + 1) * nif); rc |= dalloc(h->owned, &h->backoff, B * N * ni); rc |= dalloc(h->owned, &h->backoff_f, B * nif);
     rc |= dalloc(h->owned, &h->backoff_x, B * (N + 1) * nx); rc |= dalloc(h->owned, &h->backoff_u, B * N * nu); rc |= dalloc(h->owned, &h->K, B * N * (N + 1) * nu * nx);

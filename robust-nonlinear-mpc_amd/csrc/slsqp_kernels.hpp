@@ -62,7 +62,7 @@ struct QpArgs {
     Costs cst;
     double *Linv;             // scratch (B,N,NX,NX)
     double *ws;               // scratch (B, qp_ws_doubles(n,N,NX)): the IPM's n-vectors
-    double *state;            // scratch (B,32): QpState
+    double *state;            // scratch (B,36): QpState
     int *n_active;            // number of instances still iterating
     double *primal;           // (B,n)
     double *dual;             // (B,mb)
@@ -105,8 +105,8 @@ template <int NX, int NU>
 __host__ __device__ constexpr int qp_lds_doubles(int) { return QpLds<NX, NU>::TOTAL; }
 
 // workspace arrays per instance (doubles): 12 n-vectors + 3 (N*NX)-vectors of the solver, then the copy of an interior-point iterate
-// (6 n-vectors + 1 (N*NX)-vector: z, s_u, s_l, lambda_u, lambda_l, E'nu, nu)
-__host__ __device__ inline size_t qp_ws_doubles(int n, int N, int NX) { return (size_t)18 * n + (size_t)4 * N * NX; }
+// (6 n-vectors + 1 (N*NX)-vector: z, s_u, s_l, lambda_u, lambda_l, E'nu, nu), then the certified active set of the call's first QP (1 n-vector)
+__host__ __device__ inline size_t qp_ws_doubles(int n, int N, int NX) { return (size_t)19 * n + (size_t)4 * N * NX; }
 
 template <int NX, int NU>
 struct NeG {   // global-memory operands of the sweeps (this instance)
@@ -125,8 +125,10 @@ struct NeG {   // global-memory operands of the sweeps (this instance)
 #define STAMP(i) do {} while (0)
 #endif
 template <int NX, int NU>
-__device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool factor, double eflag, double delta, int lane, long long *dbg = nullptr,
-                                          double *bmax_out = nullptr) {
+__device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool factor_all, double eflag, double delta, int lane, long long *dbg = nullptr,
+                                          double *bmax_out = nullptr, int k0 = 0) {
+    // k0 > 0 (active-set rounds): the stages before k0 keep the factorisation of the previous round -- their D_k depend on Pi of the stages
+    // <= k + 1 only, and no entry of Pi changed there -- so their inverses are read back from the scratch like in a solve-only sweep
     double bmax = 0.0;
 #ifdef NE_STAMP
     long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
@@ -146,7 +148,7 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
         for (int r = 0; r < RA; r++) rA[r] = Ak[min(r * 64 + lane, MM - 1)];
 #pragma unroll
         for (int r = 0; r < RB; r++) rB[r] = Bk[min(r * 64 + lane, NX * NU - 1)];
-        if (!factor) {
+        if (!(factor_all && k >= k0)) {
 #pragma unroll
             for (int r = 0; r < RA; r++) rL[r] = Lg[min(r * 64 + lane, MM - 1)];
         }
@@ -156,6 +158,7 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
     };
     prefetch(0);
     for (int k = 0; k < g.N; k++) {
+        const bool factor = factor_all && k >= k0;
 #pragma unroll
         for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < MM) sA[o] = rA[r]; }
 #pragma unroll
@@ -308,7 +311,7 @@ struct QpLdsMx {   // doubles first (offsets in doubles), then floats (offsets i
 };
 
 template <int NX, int NU>
-__device__ __forceinline__ int ne_forward_mx(double *smd, const NeG<NX, NU> g, bool factor, double eflag, double delta, int lane, double *bmax_out) {
+__device__ __forceinline__ int ne_forward_mx(double *smd, const NeG<NX, NU> g, bool factor_all, double eflag, double delta, int lane, double *bmax_out, int k0 = 0) {
     double bmax = 0.0;
     using Ld = QpLdsMx<NX, NU>;
     constexpr int NZ = NX + NU, SR = NX + 2 * NZ, MM = NX * NX;
@@ -328,7 +331,7 @@ __device__ __forceinline__ int ne_forward_mx(double *smd, const NeG<NX, NU> g, b
         for (int r = 0; r < RA; r++) rA[r] = Ak[min(r * 64 + lane, MM - 1)];
 #pragma unroll
         for (int r = 0; r < RB; r++) rB[r] = Bk[min(r * 64 + lane, NX * NU - 1)];
-        if (!factor) {
+        if (!(factor_all && k >= k0)) {
 #pragma unroll
             for (int r = 0; r < RA; r++) rL[r] = Lg[min(r * 64 + lane, MM - 1)];
         }
@@ -338,6 +341,7 @@ __device__ __forceinline__ int ne_forward_mx(double *smd, const NeG<NX, NU> g, b
     };
     prefetch(0);
     for (int k = 0; k < g.N; k++) {
+        const bool factor = factor_all && k >= k0;
 #pragma unroll
         for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < MM) { sA[o] = rA[r]; if (factor) fA[o] = (float)rA[r]; else Lcur[o] = rL[r]; } }
 #pragma unroll
@@ -481,13 +485,16 @@ __device__ __forceinline__ Elem elem_of(int e, int n, int N, const double *ub, c
 // finished instances exit at once.  Splitting the former single kernel removed 340 VGPR + 382 SGPR spills.
 // ------------------------------------------------------------------------------------------------
 enum { P_INIT = 0, P_PRED = 1, P_CORR = 2, P_POL0 = 3, P_POL1 = 4, P_POL2 = 5, P_DONE = 6 };
-struct QpState {   // per instance, 32 doubles
+struct QpState {   // per instance, 36 doubles
     double phase, it, status, mu, smu, qscale, mtot, pol_round, pol_fail, warm, kst, kbox, ksign, pst, pbox, psign, ticks, fticks, tight, pad;
     double snap_call, snap_mu, snap_used, pad2;   // call that took the iterate copy (0 = none), its mu, 1 = this solve restarted from it
     double mode, cold_as, nviol, path;            // mode 1: P_INIT starts the interior point (0: an active-set attempt from the empty set);
                                                   // cold_as 1: that attempt was made; nviol: violated bounds seen by the previous round;
                                                   // path: how the solve ended up where it is (qp_stats[7])
     unsigned long long seth[4];                   // hashes of the last active sets of the current attempt (a repeat = the iteration cycles)
+    double kmin, fact_call, act1_ok, pad5;        // first stage whose block D_k the next P_POL0 factorisation must recompute (see ne_forward k0);
+                                                  // fact_call: call whose last certified solve left its factorisation (for the set in ACT) in the
+                                                  // scratch; act1_ok: ACT1 holds a certified set
 };
 
 template <int NX, int NU>
@@ -503,6 +510,19 @@ __device__ __forceinline__ NeG<NX, NU> make_neg(const QpArgs &a, int b) {
     return g;
 }
 
+// what the forward sweep of a tick does, from the instance's phase: factorise? right-hand side with the dynamics offsets? regularisation; first
+// stage to re-factorise.  The active-set rounds regularise with 1e-10 (also the P_INIT solve that serves as their round 0, so that the next
+// round can keep its leading blocks).
+struct FwdPlan { bool factor; double eflag, delta; int k0; };
+__device__ __forceinline__ FwdPlan fwd_plan(const QpState *st, int phase) {
+    FwdPlan p;
+    p.factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
+    p.eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
+    p.delta = (phase == P_POL0 || (phase == P_INIT && st->mode == 0.0)) ? 1e-10 : 0.0;
+    p.k0 = (phase == P_POL0) ? (int)st->kmin : 0;
+    return p;
+}
+
 template <int NX, int NU>
 __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -511,14 +531,14 @@ __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
     const int phase = (int)st->phase;
     if (phase == P_DONE) return;
     extern __shared__ double sm[];
-    const bool factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
-    const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
+    const FwdPlan fp = fwd_plan(st, phase);
+    const bool factor = fp.factor;
     double bmax = 0.0;
-    const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane,
+    const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane,
 #ifdef NE_STAMP_BWD
-                                     nullptr, &bmax);
+                                     nullptr, &bmax, fp.k0);
 #else
-                                     (long long *)(a.kkt + (size_t)b * 8), &bmax);
+                                     (long long *)(a.kkt + (size_t)b * 8), &bmax, fp.k0);
 #endif
     // in the refinement solves the right-hand side is E zn - e (+ a vanishing term): the dynamics residual of the polished point
     if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
@@ -536,6 +556,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
     double *Z = ws, *SU = Z + n, *SL = SU + n, *LU = SL + n, *LL = LU + n, *GC = LL + n, *CU = GC + n, *CL = CU + n;
     double *PI = CL + n, *V = PI + n, *G = V + n, *ACT = G + n, *W = ACT + n, *NUA = W + N * NX, *NUP = NUA + N * NX;
     double *SZ = NUP + N * NX, *SSU = SZ + n, *SSL = SSU + n, *SLU = SSL + n, *SLL = SLU + n, *SGC = SLL + n, *SNUA = SGC + n;   // copy of an interior-point iterate
+    double *ACT1 = SNUA + N * NX;   // active set the first QP of the previous fast-SLS call ended on (warm start of the next call's first QP)
     Costs cst = a.cst;
     cst.prox = a.prox ? a.prox[(size_t)b * a.prox_stride] : 0.0;
     QpState *stp = (QpState *)a.state + b;
@@ -566,6 +587,13 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         // warm start: the previous solve of this instance ended with a certified active set -> polish from it first
         const bool warm = a.warm && ((int)stp->status == 0) && ((int)stp->phase == P_DONE) && status == ST_INIT;
         const double *prev = a.primal + (size_t)b * n;
+        // the first QP of a call starts from the set the first QP of the previous call ended on (the un-tightened QPs of consecutive MPC steps
+        // resemble each other more than a tightened and an un-tightened one: 2.8 against 3.9 rounds, scripts/proto/as_warm_sources.py)
+        const bool from_act1 = warm && a.stat_slot == 0 && a.snap_use == 0 && stp->act1_ok != 0.0;
+        // a later QP of the same call whose previous solve was certified: same A, B, weights, and the scratch still holds the factorisation of
+        // exactly the set it starts from -- its first tick needs no factorisation at all
+        const bool keep_fact = warm && !from_act1 && a.snap_use != 0 && stp->fact_call == a.call_id && a.call_id != 0.0;
+        double set_changed = 0.0;
         double qscale = 0.0, mtot = 0.0;
 #pragma unroll 4
         for (int e = lane; e < n; e += 64) {
@@ -573,8 +601,10 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             qscale = fmax(qscale, fabs(el.q));
             mtot += (el.fu ? 1.0 : 0.0) + (el.fl ? 1.0 : 0.0);
             if (warm) {
-                double ac = ACT[e];
+                const double ac_old = ACT[e];
+                double ac = from_act1 ? ACT1[e] : ac_old;
                 if ((ac > 0.0 && !el.fu) || (ac < 0.0 && !el.fl) || !el.fr) ac = 0.0;
+                if (ac != ac_old) set_changed = 1.0;
                 const double zp = (e < NX) ? a.x0val[(size_t)b * NX + e] : prev[e];
                 const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zp);
                 const double pi = (el.fr && ac == 0.0) ? wla::fast_rcp(el.pd) : 0.0;
@@ -587,13 +617,14 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         }
         qscale = fmax(1.0, wla::wave_max(qscale));
         mtot = fmax(1.0, wla::wave_sum(mtot));
+        const bool skip_fact = keep_fact && wla::wave_max(set_changed) == 0.0;
         if (lane == 0) {
             QpState s0;
             s0.phase = (status == ST_INIT) ? (warm ? P_POL0 : P_INIT) : P_DONE; s0.it = 0; s0.status = status; s0.mu = 0; s0.smu = 0; s0.qscale = qscale;
             s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1; s0.ticks = 0; s0.fticks = 0; s0.tight = 0; s0.pad = 0;
             s0.snap_call = stp->snap_call; s0.snap_mu = stp->snap_mu; s0.snap_used = 0; s0.pad2 = 0;
             s0.mode = a.as_first ? 0.0 : 1.0; s0.cold_as = 0; s0.nviol = 0; s0.path = warm ? 10.0 : 0.0;
-            s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL;
+            s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.pad5 = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
             if (status == ST_INIT) atomicAdd(a.n_active, 1);
@@ -760,7 +791,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 in_viol |= (viol_at(e, tolv) > 0.0) ? 1 : 0;
             }
             const bool any_in = wla::wave_or(in_viol) != 0;
-            double changed = 0.0, viols = 0.0;
+            double changed = 0.0, viols = 0.0, kfirst = 1e9;
             unsigned long long hv = 0ULL;
 #pragma unroll 2
             for (int e = lane; e < n; e += 64) {
@@ -778,7 +809,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                         if (take) nac = vu > vl ? 1.0 : -1.0;
                     }
                 }
-                if (nac != ac) changed += 1.0;
+                if (nac != ac) { changed += 1.0; kfirst = fmin(kfirst, (double)max(0, e / NZ - ((e % NZ) < NX ? 1 : 0))); }   // x_k enters D_{k-1} and D_k, u_k enters D_k
                 if (nac != 0.0) {   // splitmix64 of (element, side)
                     unsigned long long x = (unsigned long long)(2 * e + (nac > 0.0 ? 1 : 0)) + 0x9E3779B97F4A7C15ULL;
                     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; hv ^= x ^ (x >> 31);
@@ -792,6 +823,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             }
             hash = hv | 1ULL;      // never 0 (0 = empty slot)
             nv = wla::wave_sum(viols);
+            s.kmin = fmin(wla::wave_min(kfirst), (double)N);
             return wla::wave_sum(changed);
         };
         // a set this attempt has already solved with: the iteration cycles
@@ -946,7 +978,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 const double pi = (el.fr && !aU && !aL) ? wla::fast_rcp(el.pd) : 0.0;
                 ACT[e] = aU ? 1.0 : (aL ? -1.0 : 0.0); PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
             }
-            phase = P_POL0;
+            phase = P_POL0; s.kmin = 0.0;
         } else if (it >= a.max_iter) { status = 1; phase = P_DONE; }
         else phase = P_PRED;
     }
@@ -978,7 +1010,12 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             }
             const double *nus = polished ? NUP : NUA;
             for (int o = lane; o < N * NX; o += 64) du[(o / NX) * SR + (o % NX)] = nus[o];
+            if (polished && a.stat_slot == 0 && a.snap_use == 0) {     // the call's first QP: its set is where the next call's first QP starts
+                for (int e = lane; e < n; e += 64) ACT1[e] = ACT[e];
+                s.act1_ok = 1.0;
+            }
         }
+        if (polished) s.fact_call = a.call_id;
         csum = wla::wave_sum(csum);
         nact = wla::wave_sum(nact);
         if (lane == 0) {
@@ -1056,10 +1093,10 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
         QpState *st = (QpState *)a.state + b;
         const int phase = (int)st->phase;
         if (phase == P_DONE) break;
-        const bool factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
-        const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
+        const FwdPlan fp = fwd_plan(st, phase);
+        const bool factor = fp.factor;
         double bmax = 0.0;
-        const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane, nullptr, &bmax);
+        const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, nullptr, &bmax, fp.k0);
         if (lane == 0) {
             if (phase == P_POL1 || phase == P_POL2) st->pbox = bmax;
             st->ticks += 1.0;
@@ -1090,10 +1127,10 @@ __global__ __launch_bounds__(64, QP_MX_WAVES_PER_SIMD) void k_ne_fwd_mx(QpArgs a
     const int phase = (int)st->phase;
     if (phase == P_DONE) return;
     extern __shared__ double sm[];
-    const bool factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
-    const double eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
+    const FwdPlan fp = fwd_plan(st, phase);
+    const bool factor = fp.factor;
     double bmax = 0.0;
-    const int f = ne_forward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), factor, eflag, phase == P_POL0 ? 1e-10 : 0.0, lane, &bmax);
+    const int f = ne_forward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, &bmax, fp.k0);
     if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
     if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { atomicAdd(a.inst_launches + 1, 1ULL); st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
 }

@@ -8,16 +8,17 @@ from problems import run_oracle_closed_loop
 m = get_model("rocket")
 N, B = 20, 3
 rng = np.random.default_rng(23)
-x0 = np.stack([m.x_ref + 0.04 * (m.x_ub - m.x_lb) * rng.uniform(-1, 1, m.nx) for _ in range(B)])
+amp = float(sys.argv[1]) if len(sys.argv) > 1 else 0.04
+x0 = np.stack([m.x_ref + amp * (m.x_ub - m.x_lb) * rng.uniform(-1, 1, m.nx) for _ in range(B)])
 for sls in (1, None):
-    for cap in (3, 8, 20):
+    for cap in (20,):
         cl = ClosedLoopMPC(m, N, B, rti=-1, fast_sls_rti_steps=sls)
         cl.f.opts.scp_eps = 1e-8
         cl.f.opts.max_scp_iter = cap
         out = cl.run(x0, 1, None)
         dm = cl.f.get("scp_delta_max", ())
         cl.close()
-        for b in range(B if cap <= 8 else 1):
+        for b in range(B):
             t0 = time.time()
             ref = run_oracle_closed_loop(m, N, x0[b], 1, -1, sls, None, scp_eps=1e-8, max_scp_iter=cap)
             ex = np.max(np.abs(out["nominal_trajectory_x"][b].transpose(2, 1, 0) - ref["nominal_x"]))

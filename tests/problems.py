@@ -130,7 +130,46 @@ def host_jac(mid, x, u):
     return DO.jac(mid, np.asarray(x, dtype=float), np.asarray(u, dtype=float))
 
 
-def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=None, scp_eps=1e-10, max_scp_iter=100, X_nom=None, U_nom=None):
+class _Info:
+    def __init__(self, ok, its, obj):
+        self.status, self.iter, self.polish_status, self.obj_val, self.setup_time_ms, self.solve_time_ms = (1 if ok else -2), its, 0, obj, 0.0, 0.0
+
+
+def ipm_backend(qp, l, u):
+    """Exact solve of the oracle QP object's problem by the dense Mehrotra interior point of tests/ref_ipm.py (nothing in common with the ADMM
+    restatement or the GPU solver), returned in the reference's row layout (qp_jit.py:101-123: per stage nx dynamics rows + ni rows of G = [I;-I],
+    then the terminal rows, then the x0 pin) with OSQP's sign convention for y.  Box constraints G = [I;-I] only."""
+    from ref_ipm import build_equalities, qp_box
+    d = qp.d
+    nx, nu, N, ni = d.nx, d.nu, d.N, d.ni
+    nz, SR = nx + nu, nx + d.ni
+    n = nz * N + nx
+    hi, lo = np.full(n, 1e20), np.full(n, -1e20)
+    for k in range(N):
+        hi[k * nz:(k + 1) * nz] = u[k * SR + nx:k * SR + nx + nz]
+        lo[k * nz:(k + 1) * nz] = -u[k * SR + nx + nz:k * SR + nx + 2 * nz]
+    hi[N * nz:], lo[N * nz:] = u[N * SR:N * SR + nx], -u[N * SR + nx:N * SR + 2 * nx]
+    x0val = 0.5 * (l[-nx:] + u[-nx:])
+    viol = np.maximum(x0val - hi[:nx], lo[:nx] - x0val).max()          # the reference keeps the stage-0 box rows beside the pin
+    hi[:nx], lo[:nx] = 1e20, -1e20
+    c = np.stack([-0.5 * (u[k * SR:k * SR + nx] + l[k * SR:k * SR + nx]) for k in range(N)])
+    A = qp.A.reshape(N, nx, nx); B = qp.B.reshape(N, nx, nu)
+    E, e = build_equalities(A, B, c, x0val)
+    Pd = 2.0 * np.concatenate([np.concatenate([np.diag(qp.Q.reshape(nx, nx)), np.diag(qp.R.reshape(nu, nu))])] * N + [np.diag(qp.Qf.reshape(nx, nx))])
+    if viol > 1e-9:
+        return np.zeros(n), np.zeros(len(l)), _Info(False, 0, 0.0)
+    z, nu_, lu, ll, ok, its = qp_box(Pd, qp.q, E, e, lo, hi)
+    y = np.zeros(len(l))
+    for k in range(N):
+        y[k * SR:k * SR + nx] = nu_[nx * (k + 1):nx * (k + 2)]
+        y[k * SR + nx:k * SR + nx + nz] = lu[k * nz:(k + 1) * nz]
+        y[k * SR + nx + nz:k * SR + nx + 2 * nz] = ll[k * nz:(k + 1) * nz]
+    y[N * SR:N * SR + nx] = lu[N * nz:]; y[N * SR + nx:N * SR + 2 * nx] = ll[N * nz:]
+    y[-nx:] = nu_[:nx]
+    return z, y, _Info(ok, its, float(0.5 * z @ (Pd * z) + qp.q @ z))
+
+
+def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=None, scp_eps=1e-10, max_scp_iter=100, X_nom=None, U_nom=None, qp_backend=None):
     """Single-instance CPU closed loop: SCP_SLS.solve (solver/SCP_SLS_jit.py:65-152) with the zero-order roll-out initialiser,
     reset_warm_start (:500-551) and the plant update of the closed-loop scripts."""
     from oracle import oracle as O
@@ -138,6 +177,8 @@ def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=Non
     E = np.stack([m.E] * (N + 1))
     fs = O.OracleFastSLS(d, m.G, m.Gf, m.g, m.gf, E, m.Q, m.R, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, settings or O.tight_settings())
     fs.set_rti_steps(sls_steps)
+    if qp_backend == "ipm":
+        fs.qp.backend = ipm_backend
     mid = m.model_id
     if X_nom is not None:         # caller's first nominal (the role of IPOPT's in SCP_SLS.solve_nominal_trajectory, SCP_SLS_jit.py:161-188)
         X, U = np.array(X_nom, dtype=float), np.array(U_nom, dtype=float)
@@ -148,7 +189,7 @@ def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=Non
             X[k + 1] = host_ddyn(mid, X[k], U[k])
     Hd = np.concatenate([np.concatenate([np.diag(m.Q), np.diag(m.R)])] * N + [np.diag(m.Qf)])
     xm = np.asarray(x0, dtype=float).copy()
-    log = dict(state=[], u0=[], nominal_x=[], nominal_u=[], backoff_x=[], success=[], scp_iterations=[], primal_infeasibility=[])
+    log = dict(state=[], u0=[], nominal_x=[], nominal_u=[], backoff_x=[], success=[], scp_iterations=[], primal_infeasibility=[], oracle_qp_converged=[])
     converge = rti is None or rti <= 0          # SCP_SLS default rti = -1: until |delta|inf < epsilon_convergence (SCP_SLS_jit.py:113-135)
     for i in range(steps):
         if i > 0:
@@ -158,6 +199,7 @@ def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=Non
         ok = True
         converged = False
         it_used = 0
+        qp_conv = True
         for ii in range(max_scp_iter if converge else rti):
             it_used = ii
             A = np.zeros((N, m.nx, m.nx)); Bm = np.zeros((N, m.nx, m.nu)); c = np.zeros((N, m.nx))
@@ -170,6 +212,11 @@ def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=Non
             fs.update_linear_cost(2.0 * Hd * y_nom)
             sol = fs.solve(X[0] - xm)
             ok = bool(sol["success"])
+            # fast_SLS.solve ignores the outcome of its LAST forward solve (fast_SLS_jit.py:293, 311): when the oracle's ADMM restatement gives up
+            # there (iteration cap at eps 1e-9 on a hard tightened QP; OSQP's own default eps 1e-3 would have returned), `success` stays True and
+            # the step carries the previous QP's primal -- not the optimum.  Flagged so that tests do not hold the GPU's exact optimum against it.
+            if ok and fs.qp.last_info.status != 1:
+                qp_conv = False
             if not ok:
                 break
             X = X + sol["primal_x"].T
@@ -180,6 +227,7 @@ def run_oracle_closed_loop(m, N, x0, steps, rti, sls_steps, W=None, settings=Non
         if converge:
             ok = ok and converged
         log["scp_iterations"].append(it_used)
+        log["oracle_qp_converged"].append(qp_conv)
         # SCP_SLS.socp_step's primal_infeasibility = max_k,i (f(x_k,u_k) - x_{k+1})_i of the updated nominal (SCP_SLS_jit.py:449-456), signed max
         log["primal_infeasibility"].append(max(float(np.max(host_ddyn(mid, X[k], U[k]) - X[k + 1])) for k in range(N)))
         log["state"].append(X[0].copy()); log["u0"].append(U[0].copy()); log["nominal_x"].append(X.copy()); log["nominal_u"].append(U.copy())

@@ -266,3 +266,24 @@ def test_oracle_c_threaded_rti_batch_equals_the_python_driven_oracle():
         assert done == 5 and ok.all()
         for b in range(5):
             assert np.array_equal(P[b], ref[b]["primal_vec"])
+
+
+@pytest.mark.parametrize("model", ["pendulum", "rocket"])
+def test_closed_loop_oracle_back_ends_agree(model):
+    """The closed-loop oracle can solve its QPs with the ADMM restatement (default) or with the dense interior point of tests/ref_ipm.py
+    (problems.ipm_backend, used where the ADMM does not converge): on a fast-SLS RTI step both give the same primal, duals and back-offs."""
+    from oracle import oracle as O
+    from problems import ipm_backend
+    inst = make_instance(model, 1, 0.5)
+    m = inst.m
+    r1 = run_oracle_fastsls(inst, 1)
+    f = O.OracleFastSLS(oracle_dims(inst), m.G, m.Gf, m.g, m.gf, inst.E, m.Q, m.R, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, O.tight_settings())
+    f.qp.backend = ipm_backend
+    f.set_rti_steps(1)
+    f.update_dynamics_list(inst.A, inst.B, inst.E, inst.g_list, inst.c)
+    f.update_linear_cost(inst.q)
+    r2 = f.solve(inst.x0_arg)
+    assert r1["success"] and r2["success"]
+    assert np.max(np.abs(r1["primal_vec"] - r2["primal_vec"])) < 1e-7 * max(1.0, np.abs(r1["primal_vec"]).max())
+    assert np.max(np.abs(r1["dual_vec"] - r2["dual_vec"])) < 1e-6 * max(1.0, np.abs(r1["dual_vec"]).max())
+    assert np.allclose(r1["backoff"], r2["backoff"], rtol=1e-7, atol=1e-10)

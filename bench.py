@@ -178,11 +178,11 @@ class ClosedLoopSlices:
 
     def kernel_timing(self):
         tot = [0.0, 0, 0, 0]
-        self.fwd_factor_sweeps = 0
+        self.fwd_factor_sweeps = self.factor_stages = self.qp_solves = 0
         for cl in self.cl:
             ms, n = cl.f.kernel_timing()
             tot[0] += ms; tot[1] += n; tot[2] += cl.f.fwd_instance_sweeps; tot[3] += cl.f.mx_retries
-            self.fwd_factor_sweeps += cl.f.fwd_factor_sweeps
+            self.fwd_factor_sweeps += cl.f.fwd_factor_sweeps; self.factor_stages += cl.f.factor_stages; self.qp_solves += cl.f.qp_solves
         return tuple(tot)
 
     def close(self):
@@ -293,13 +293,27 @@ def main():
             return f
         return SlicedDeviceBatch(make_solver, batch, n_slices), batch
 
-    per_inst = 8 * (N * m.nx * nz + 2 * n_var + N * m.nx)      # algorithmic bytes of one instance forward sweep: A_k, B_k in, rhs slices in, u out
+    # Work figures of the dominant kernel k_qp_solve (one launch = the whole QP solve of every instance of a slice: all its block-tridiagonal
+    # solves and the logic between them), from device counters:
+    #   fp64 flops   28.6 kflop per factorised stage (T = M1 Dinv, D_k build, Gauss-Jordan inverse; rocket, scaled with nx^3) + 2 kflop per
+    #                substitution stage of a forward and of a backward sweep (scaled with nx^2)                        [DESIGN.md section 4]
+    #   bytes        SURVEY.md 8(d): 93 656 B compulsory per rocket QP solve (A, B, q, l, u in; x, y out); beside it the bytes the kernel's sweeps
+    #                must move at its LDS capacity, per instance forward sweep: A_k, B_k in, rhs slices in, u out (round 1's accounting)
+    per_sweep_bytes = 8 * (N * m.nx * nz + 2 * n_var + N * m.nx)
+    kf, ks = 28.6e3 * (m.nx / 17.0) ** 3, 2.0e3 * (m.nx / 17.0) ** 2
 
-    def roof_block(fwd_ms_total, launches, inst_sweeps):
-        fwd_ms = fwd_ms_total / max(1, launches)
-        alg = per_inst * float(inst_sweeps) / max(1, launches)
-        ach = alg / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
-        return {"achieved": ach, "frac": ach / 8000.0, "avg_launch_ms": fwd_ms, "launches": launches, "algorithmic_bytes_per_launch": alg}
+    def roof_block(ms_total, launches, inst_sweeps, factor_stages, qp_solves):
+        L = max(1, launches)
+        ms = ms_total / L
+        flops = (factor_stages * kf + 2.0 * inst_sweeps * N * ks) / L
+        tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        alg = QP_BYTES[args.model] * float(qp_solves) / L
+        work = per_sweep_bytes * float(inst_sweeps) / L
+        return {"achieved": tf, "frac": tf / 78.6, "avg_launch_ms": ms, "launches": launches, "flops_per_launch": flops,
+                "qp_solves_per_launch": float(qp_solves) / L, "block_solves_per_qp": float(inst_sweeps) / max(1, qp_solves),
+                "factorised_stages_per_qp": float(factor_stages) / max(1, qp_solves),
+                "hbm": {"algorithmic_bytes_per_launch": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "frac_of_8TBps": alg / (ms * 1e-3) / 8e12 if ms > 0 else 0.0,
+                        "sweep_bytes_per_launch": work, "sweep_GBps": work / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}}
 
     out = {}
     if args.workload == "closed_loop":
@@ -337,8 +351,8 @@ def main():
         workload = (f"{args.model} N={N} batch={B}/GPU synthetic instances (seeded perturbations of one nominal; 0-8 active inequalities), fast-SLS RTI step "
                     f"(update_dynamics + update_linear_cost + solve: 2 QP solves + 1 SLS sweep per instance), no linearisation")
         extra_cfg = {}
-    fwd_total_ms, fwd_launches, inst_sweeps, mx_retries = dev.kernel_timing()
-    fact_sweeps = dev.fwd_factor_sweeps
+    k_ms, k_launches, inst_sweeps, mx_retries = dev.kernel_timing()
+    fact_stages, qp_solves = dev.factor_stages, dev.qp_solves
     if world > 1:
         tmax = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -358,20 +372,20 @@ def main():
         st = dev.get("status", (), np.int32)
         out["config"]["last_qp_solved_frac"] = float(np.mean((st == 0) | (st == 4)))
         out["config"]["last_qp_certified_frac"] = float(np.mean(st == 0))
-        # dominant kernel: k_ne_fwd (block-tridiagonal forward sweep; re-factorises in about half of its launches).  A launch moves the algorithmic
-        # bytes of every instance it works on (device counter of instance sweeps / launches); time = HIP events around every launch on the launching stream.
-        rb = roof_block(fwd_total_ms, fwd_launches, inst_sweeps)
-        traffic, tsrc = read_traffic("pmc_traffic.json", "k_ne_fwd_bytes_per_launch")
+        # dominant kernel: k_qp_solve; time = HIP events around every launch on the launching stream (opts.time_kernels), work = device counters.
+        # The kernel is bound by vector-ALU instruction issue: its roof is the fp64 peak (matrix = vector = 78.6 TFLOP/s).
+        rb = roof_block(k_ms, k_launches, inst_sweeps, fact_stages, qp_solves)
+        traffic, tsrc = read_traffic("pmc_traffic.json", "k_qp_solve_bytes_per_launch")
         calls = args.steps * n_sl
         sweep_flop = SWEEP_MFLOP * 1e6 * (m.nx / 17.0) ** 3 * (N / 20.0) ** 2
-        fp64 = (fact_sweeps * N * 28.6e3 * (m.nx / 17.0) ** 3 + (2 * inst_sweeps - fact_sweeps) * N * 2.0e3 * (m.nx / 17.0) ** 2 + args.steps * B * sweep_flop) / dt / 1e12
-        out["roofline"] = dict({"bound": "hbm", "kernel": "k_ne_fwd", "peak": 8000.0, "unit": "GB/s", "traffic": traffic, "traffic_source": tsrc}, **rb)
+        step_tf = (fact_stages * kf + 2.0 * inst_sweeps * N * ks + args.steps * B * sweep_flop) / dt / 1e12
+        out["roofline"] = dict({"bound": "mfma", "kernel": "k_qp_solve", "peak": 78.6, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": tsrc}, **rb)
         out["roofline"].update({
-            "qp_solve": {"avg_ms": sum(a["qp"] for a in acc) / (2 * calls), "instances": B / n_sl, "algorithmic_bytes": QP_BYTES[args.model] * B / n_sl,
+            "note": "fp64: matrix peak = vector peak on MI355X; the kernel issues its block products on the matrix core and is bound by vector-ALU issue",
+            "qp_solve": {"avg_ms": sum(a["qp"] for a in acc) / (2 * calls), "instances": B / n_sl,
                          "note": "one solve call = one slice; slices run concurrently, so these times overlap"},
-            # second ceiling: fp64 work of the timed region / wall time against the vector = matrix fp64 peak.  Per instance sweep of N stages:
-            # 28.6 kflop per factorising stage, 2 kflop per forward / backward substitution stage; SLS sweep 9.0 Mflop per rocket instance
-            "fp64": {"achieved_TFLOPs": fp64, "peak_TFLOPs": 78.6, "frac": fp64 / 78.6, "note": "vector fp64 peak = matrix fp64 peak on MI355X (BASELINE.md, AMD public figure)"},
+            # the whole step: fp64 work of the timed region (QP kernel + 9.0 Mflop per rocket instance for the SLS sweep) over wall time
+            "whole_step_fp64": {"achieved_TFLOPs": step_tf, "peak_TFLOPs": 78.6, "frac": step_tf / 78.6},
             "sweep_avg_launch_ms": sum(a["sweep"] for a in acc) / calls, "slice_gpu_ms_per_step": [round(a["total"] / args.steps, 2) for a in acc]})
         cpu_data = None
         if args.workload == "closed_loop" and not args.no_cpu and world == 1:
@@ -399,9 +413,10 @@ def main():
                     torch.cuda.synchronize()
                     dt1 = time.perf_counter() - t1
                     ms1, n1, sw1, _ = one.kernel_timing()
+                    fs1, qs1 = one.factor_stages, one.qp_solves
                     one.close()
-                    tr1, ts1 = read_traffic("pmc_traffic_single_slice.json", "k_ne_fwd_bytes_per_launch")
-                    out["roofline"]["single_slice"] = dict(roof_block(ms1, n1, sw1), traffic=tr1, traffic_source=ts1, ms_per_step=1e3 * dt1 / args.steps,
+                    tr1, ts1 = read_traffic("pmc_traffic_single_slice.json", "k_qp_solve_bytes_per_launch")
+                    out["roofline"]["single_slice"] = dict(roof_block(ms1, n1, sw1, fs1, qs1), traffic=tr1, traffic_source=ts1, ms_per_step=1e3 * dt1 / args.steps,
                                                            gpu_ms_per_step={k: a1[0][k] / args.steps for k in a1[0]},
                                                            note="same closed-loop steps with the whole batch as one slice, after the timed region")
             except Exception as e:      # never lose the headline line to an auxiliary measurement

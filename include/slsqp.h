@@ -64,7 +64,7 @@ typedef struct {
     int want_K;          /* also keep K (N,N+1,nu,nx) for slsqp_get */
     int warm_start;      /* 1 (default): the first QP of a call first tries an active-set polish from the instance's previous
                             certified solution (KKT-verified, falls back to the interior point); later QPs of a call always do */
-    int warm_rounds;     /* active-set correction rounds a warm attempt may use before falling back (default 6) */
+    int warm_rounds;     /* active-set correction rounds a warm attempt may use before falling back (default 10) */
     int max_scp_iter;    /* MAX_ITER_SCP (100, SCP_SLS_jit.py:47): cap of the SCP loop of slsqp_cl_step in converge mode (rti <= 0) */
     double scp_eps;      /* epsilon_convergence (1e-10, SCP_SLS_jit.py:29): SCP converged when |delta_vec|inf < scp_eps */
     int precision;       /* 0 (default): fp64 throughout.  1: mixed -- block factorisations, stored inverses and substitutions in fp32,
@@ -72,7 +72,7 @@ typedef struct {
                             that do not certify are solved again in fp64 (BASELINE config 3, "fp32 vs fp64") */
     int as_first;        /* 1 (default): a cold QP solve first runs the active-set iteration from the empty set (round 0 = the equality-constrained
                             optimum), certificate-checked like every polish, and only falls back to the interior point when that fails */
-    int as_rounds;       /* correction rounds such an attempt may use (default 8) */
+    int as_rounds;       /* correction rounds such an attempt may use (default 12) */
     int as_max_viol;     /* an active-set attempt is abandoned when one of its solves leaves more violated bounds than this (default 64), or more
                             than twice the previous round's + 8: a set that pins both ends of a dynamics row makes the solve blow up */
     int ipm_restart;     /* 1 (default): QPs after the first of a fast-SLS call (same A, B, q, tightened bounds) whose warm active-set attempt
@@ -176,10 +176,12 @@ int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta_f, double 
    measured with HIP events on the handle's stream: [0] total, [1] QP kernel(s), [2] sweep kernel, [3] other,
    [4] linearisation of the last slsqp_cl_step (the reference's t_jac, SCP_SLS_jit.py:268,339-341).  ms5 must hold 5 doubles. */
 int slsqp_last_timing(slsqp_handle *h, double *ms5);
-/* accumulated since the last call: [0] total ms of k_ne_fwd launches (HIP events around each launch, handle's stream),
-   [1] number of launches, [2] instances re-solved in fp64 after a mixed-precision attempt, [3] instance-sweeps those launches did,
-   [4] how many of them factorised (device counters); resets the accumulators.  out must hold 5 doubles. */
-int slsqp_kernel_timing(slsqp_handle *h, double *out5);
+/* accumulated since the last call (opts.time_kernels = 1 for [0], [1]): [0] total ms of the launches of the dominant QP kernel (k_qp_solve: one
+   launch per QP solve; with the tick kernels: k_ne_fwd) from HIP events around each launch on the handle's stream, [1] number of those launches,
+   [2] instances re-solved in fp64 after a mixed-precision attempt, and device counters of the work done: [3] instance forward sweeps (= backward
+   sweeps), [4] how many of them factorised, [5] stages factorised (a factorising sweep of an active-set round re-does only the stages from the
+   first changed one on), [6] QP solves (instances x launches of k_qp_solve), [7] reserved; resets the accumulators.  out must hold 8 doubles. */
+int slsqp_kernel_timing(slsqp_handle *h, double *out8);
 void *slsqp_stream(slsqp_handle *h); /* hipStream_t, for callers that share device buffers */
 
 #ifdef __cplusplus

@@ -195,4 +195,41 @@ DYN_HD void ddyn_jac_column(const double *x, const double *u, int dir, double *c
     for (int i = 0; i < NX; i++) { col[i] = Xp[i].d; if (f) f[i] = Xp[i].v; }
 }
 
+// The same Jacobian column in two steps that a GPU thread can hold in registers (the one-step version above carries X, k, t, acc as dual numbers:
+// 288 registers for the rocket, 189 of them spilled): (1) ddyn_stages: the plain RK4 step, keeping the three intermediate stage points;
+// (2) ddyn_tangent: the tangent of the step along one direction, the stage points' values read back instead of carried.
+template <int MODEL>
+DYN_HD void ddyn_stages(const double *x, const double *u, double *stage /* 3*NX: x + h/2 k1, x + h/2 k2, x + h k3 */, double *xp) {
+    constexpr int NX = Dims<MODEL>::NX;
+    const double h = RK4_H;
+    double k[NX], t[NX], acc[NX];
+    ode<MODEL, double>(x, u, k);
+    for (int i = 0; i < NX; i++) { acc[i] = k[i]; t[i] = x[i] + 0.5 * h * k[i]; stage[i] = t[i]; }
+    ode<MODEL, double>(t, u, k);
+    for (int i = 0; i < NX; i++) { acc[i] = acc[i] + 2.0 * k[i]; t[i] = x[i] + 0.5 * h * k[i]; stage[NX + i] = t[i]; }
+    ode<MODEL, double>(t, u, k);
+    for (int i = 0; i < NX; i++) { acc[i] = acc[i] + 2.0 * k[i]; t[i] = x[i] + h * k[i]; stage[2 * NX + i] = t[i]; }
+    ode<MODEL, double>(t, u, k);
+    for (int i = 0; i < NX; i++) xp[i] = x[i] + (1.0 / 6.0) * (acc[i] + k[i]) * h;
+}
+template <int MODEL>
+DYN_HD void ddyn_tangent(const double *x, const double *u, const double *stage, int dir, double *col) {
+    constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
+    const double h = RK4_H;
+    Dual T[NX], U[NU], K[NX];
+    double acc[NX];
+    for (int i = 0; i < NU; i++) U[i] = Dual(u[i], NX + i == dir ? 1.0 : 0.0);
+    for (int i = 0; i < NX; i++) { T[i] = Dual(x[i], i == dir ? 1.0 : 0.0); acc[i] = 0.0; }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        ode<MODEL, Dual>(T, U, K);
+        const double w = (s == 0 || s == 3) ? 1.0 : 2.0, cn = (s == 2) ? h : 0.5 * h;
+        for (int i = 0; i < NX; i++) {
+            acc[i] += w * K[i].d;
+            if (s < 3) T[i] = Dual(stage[s * NX + i], (i == dir ? 1.0 : 0.0) + cn * K[i].d);
+        }
+    }
+    for (int i = 0; i < NX; i++) col[i] = (i == dir ? 1.0 : 0.0) + (h / 6.0) * acc[i];
+}
+
 }  // namespace dyn

@@ -30,8 +30,8 @@ extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
     o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-6; o->conv_tol = 1e-3;
-    o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 6;
-    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0; o->as_first = 1; o->as_rounds = 8; o->as_max_viol = 64; o->ipm_restart = 1;
+    o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 10;
+    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0; o->as_first = 1; o->as_rounds = 12; o->as_max_viol = 64; o->ipm_restart = 1;
 }
 
 struct slsqp_handle {
@@ -50,6 +50,7 @@ struct slsqp_handle {
     int *scp_active, *scp_success, *scp_iters, *pending_reset, *scp_upd; double *scp_dmax;
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
     int *retry; int mx_retry, mx_retry_total;
+    double *lin_stage;          // (B,N,3,nx) intermediate RK4 stage points of the linearisation (k_lin_val -> k_lin_tan)
     double call_id;             // counts fast-SLS calls (validity of the interior-point iterate copies, QpArgs::call_id)
     int *qpstat;                // (B,2,8) per-QP statistics, see QpArgs::qpstat
     int *stale;                 // (B) bit 0: eta / eta_f, bit 1: K hold values from before the last slsqp_reset (zeroed lazily on slsqp_get)
@@ -131,8 +132,8 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(h->owned, &h->retry, B); h->mx_retry = 0; h->mx_retry_total = 0;
     rc |= dalloc(h->owned, &h->nom_st, B * 12); rc |= dalloc(h->owned, &h->nom_need_lin, B); rc |= dalloc(h->owned, &h->nom_status, B); rc |= dalloc(h->owned, &h->nom_iters, B);
     rc |= dalloc(h->owned, &h->mapA, (size_t)N * nx * nx); rc |= dalloc(h->owned, &h->mapB, (size_t)N * nx * nu);
-    rc |= dalloc(h->owned, &h->inst_launches, (size_t)2); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
-    rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
+    rc |= dalloc(h->owned, &h->inst_launches, (size_t)4); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
+    rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
     h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { free_all(h->owned); hipStreamDestroy(h->st); delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
@@ -538,13 +539,14 @@ extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms5) {
     ms5[0] = h->t_total; ms5[1] = h->t_qp; ms5[2] = h->t_sweep; ms5[3] = h->t_total - h->t_qp - h->t_sweep; ms5[4] = h->t_jac;
     return 0;
 }
-extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out3) {
-    unsigned long long il[2] = {0, 0};
+extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out8) {
+    unsigned long long il[4] = {0, 0, 0, 0};
     hipSetDevice(h->dev);
     hipMemcpyAsync(il, h->inst_launches, sizeof(il), hipMemcpyDeviceToHost, h->st);
     hipMemsetAsync(h->inst_launches, 0, sizeof(il), h->st);
     hipStreamSynchronize(h->st);
-    out3[0] = h->t_fwd; out3[1] = (double)h->n_fwd; out3[2] = (double)h->mx_retry_total; out3[3] = (double)il[0]; out3[4] = (double)il[1];
+    out8[0] = h->t_fwd; out8[1] = (double)h->n_fwd; out8[2] = (double)h->mx_retry_total; out8[3] = (double)il[0]; out8[4] = (double)il[1];
+    out8[5] = (double)il[2]; out8[6] = (double)il[3]; out8[7] = 0.0;
     h->t_fwd = 0; h->n_fwd = 0; h->mx_retry_total = 0;
     return 0;
 }
@@ -628,11 +630,23 @@ static int linearize_impl(slsqp_handle *h, const double *X, const double *U, int
         HIPCHK(hipMemcpyAsync(tmp + nX, U, sizeof(double) * nU, hipMemcpyHostToDevice, h->st));
         dX = tmp; dU = tmp + nX;
     }
-    LinArgs a{h->B, d.N, dX, dU, h->g_raw, h->gf_raw, costs_of(h), h->A, h->Bm, h->c, h->g, h->gN, h->q, run};
+    LinArgs a{h->B, d.N, dX, dU, h->g_raw, h->gf_raw, costs_of(h), h->A, h->Bm, h->c, h->g, h->gN, h->q, run, h->lin_stage};
+    static const bool two_step = getenv("SLSQP_LIN_ONE_STEP") ? atoi(getenv("SLSQP_LIN_ONE_STEP")) == 0 : true;
     const int grid = 2048, blk = 128;
-    if (h->model_id == 0) { hipLaunchKernelGGL((k_lin_jac<0>), dim3(grid), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_vec<4, 1>), dim3(grid), dim3(256), 0, h->st, a); }
-    else if (h->model_id == 1) { hipLaunchKernelGGL((k_lin_jac<1>), dim3(grid), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_vec<13, 4>), dim3(grid), dim3(256), 0, h->st, a); }
-    else { hipLaunchKernelGGL((k_lin_jac<2>), dim3(grid), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_vec<17, 4>), dim3(grid), dim3(256), 0, h->st, a); }
+    const int gval = (int)((B * d.N + blk - 1) / blk);
+    if (h->model_id == 0) {
+        if (two_step) { hipLaunchKernelGGL((k_lin_val<0>), dim3(gval), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_tan<0>), dim3(grid), dim3(blk), 0, h->st, a); }
+        else hipLaunchKernelGGL((k_lin_jac<0>), dim3(grid), dim3(blk), 0, h->st, a);
+        hipLaunchKernelGGL((k_lin_vec<4, 1>), dim3(grid), dim3(256), 0, h->st, a);
+    } else if (h->model_id == 1) {
+        if (two_step) { hipLaunchKernelGGL((k_lin_val<1>), dim3(gval), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_tan<1>), dim3(grid), dim3(blk), 0, h->st, a); }
+        else hipLaunchKernelGGL((k_lin_jac<1>), dim3(grid), dim3(blk), 0, h->st, a);
+        hipLaunchKernelGGL((k_lin_vec<13, 4>), dim3(grid), dim3(256), 0, h->st, a);
+    } else {
+        if (two_step) { hipLaunchKernelGGL((k_lin_val<2>), dim3(gval), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_tan<2>), dim3(grid), dim3(blk), 0, h->st, a); }
+        else hipLaunchKernelGGL((k_lin_jac<2>), dim3(grid), dim3(blk), 0, h->st, a);
+        hipLaunchKernelGGL((k_lin_vec<17, 4>), dim3(grid), dim3(256), 0, h->st, a);
+    }
     BoundsArgs ba{h->B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->ubg, h->lbg, 1e-10, run};
     hipLaunchKernelGGL(k_set_bounds, dim3(1024), dim3(256), 0, h->st, ba);
     HIPCHK(hipGetLastError());

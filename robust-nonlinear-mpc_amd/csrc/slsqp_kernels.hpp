@@ -78,7 +78,8 @@ struct QpArgs {
     int warm;                 // 1: try an active-set polish from the previous solution of each instance first
     const double *prox;       // per-instance proximal weight added to the diagonal cost (element b * prox_stride), or NULL
     int prox_stride;
-    unsigned long long *inst_launches;   // [0] += 1 per instance forward sweep, [1] += 1 per factorising one (roofline accounting of bench.py)
+    unsigned long long *inst_launches;   // [0] += 1 per instance forward sweep, [1] += 1 per factorising one, [2] += stages it factorised, [3] += QP solves
+                                         // (roofline accounting of bench.py)
     int *qpstat;              // (B,2,8) or NULL: per instance and slot [its, block solves, factorising ones, active inequality rows, started warm,
     int stat_slot;            //   active-set correction rounds, status, fell back to the interior point]; slot = 0 first QP of a fast-SLS call, 1 its last QP
     int snap_take;            // 1: keep a copy of this solve's interior-point iterate once mu <= snap_mu * max(1,|q|inf) (start for the next QP of the call)
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
 #endif
     // in the refinement solves the right-hand side is E zn - e (+ a vanishing term): the dynamics residual of the polished point
     if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
-    if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { atomicAdd(a.inst_launches + 1, 1ULL); st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
+    if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { atomicAdd(a.inst_launches + 1, 1ULL); atomicAdd(a.inst_launches + 2, (unsigned long long)(a.N - fp.k0)); st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
 }
 
 // first = 1: set up the instance (x0-pin check, starting rhs); else consume the solve of the current phase.
@@ -1083,7 +1084,7 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
     extern __shared__ double sm[];
     phase_update<NX, NU>(a, 1, b, lane);
     wla::wsync_mem();
-    unsigned long long n_sweeps = 0, n_factor = 0;
+    unsigned long long n_sweeps = 0, n_factor = 0, n_fstages = 0;
     for (int t = 0; t < max_ticks; t++) {
         // The instance index and the lane id are laundered through empty asm statements at the head of every part: nothing computed from them
         // is loop-invariant for the compiler then, so it cannot hoist the phase logic's per-element loads (bounds, weights, linear cost) out of
@@ -1102,7 +1103,7 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
             st->ticks += 1.0;
             if (factor) { st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; }
         }
-        n_sweeps++; n_factor += factor ? 1 : 0;
+        n_sweeps++; n_factor += factor ? 1 : 0; n_fstages += factor ? (unsigned long long)(a.N - fp.k0) : 0ULL;
         wla::wsync_mem();
         asm volatile("" : "+s"(b));
         asm volatile("" : "+v"(lane));
@@ -1113,7 +1114,7 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
         phase_update<NX, NU>(a, 0, b, lane);
         wla::wsync_mem();
     }
-    if (lane == 0 && n_sweeps) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); }
+    if (lane == 0) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); atomicAdd(a.inst_launches + 2, n_fstages); atomicAdd(a.inst_launches + 3, 1ULL); }
 }
 
 #ifndef QP_MX_WAVES_PER_SIMD
@@ -1132,7 +1133,7 @@ __global__ __launch_bounds__(64, QP_MX_WAVES_PER_SIMD) void k_ne_fwd_mx(QpArgs a
     double bmax = 0.0;
     const int f = ne_forward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, &bmax, fp.k0);
     if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
-    if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { atomicAdd(a.inst_launches + 1, 1ULL); st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
+    if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { atomicAdd(a.inst_launches + 1, 1ULL); atomicAdd(a.inst_launches + 2, (unsigned long long)(a.N - fp.k0)); st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
 }
 template <int NX, int NU>
 __global__ __launch_bounds__(64) void k_ne_bwd_phase_mx(QpArgs a) {
@@ -1528,7 +1529,42 @@ struct LinArgs {
     Costs cst;
     double *A, *Bm, *c, *g, *gN, *q;
     const int *run;   // (B) 1 = linearise this instance (NULL = all)
+    double *stage;    // scratch (B,N,3,NX): intermediate RK4 stage points of every (instance, stage), k_lin_val -> k_lin_tan
 };
+// linearisation in two kernels: values (one thread per (instance, stage): RK4 step, its three intermediate points, the defect c_k) ...
+template <int MODEL>
+__global__ __launch_bounds__(128) void k_lin_val(LinArgs a) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
+    const size_t tot = (size_t)a.B * a.N;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+        const int k = t % a.N, b = t / a.N;
+        if (a.run && !a.run[b]) continue;
+        const double *xg = a.X + ((size_t)b * (a.N + 1) + k) * NX, *ug = a.U + ((size_t)b * a.N + k) * NU;
+        double x[NX], u[NU], st[3 * NX], f[NX];
+        for (int i = 0; i < NX; i++) x[i] = xg[i];
+        for (int i = 0; i < NU; i++) u[i] = ug[i];
+        dyn::ddyn_stages<MODEL>(x, u, st, f);
+        double *sg = a.stage + t * 3 * NX, *c = a.c + t * NX;
+        for (int i = 0; i < 3 * NX; i++) sg[i] = st[i];
+        for (int i = 0; i < NX; i++) c[i] = f[i] - xg[NX + i];
+    }
+}
+// ... and tangents (one thread per (instance, stage, direction): forward-mode AD through the four ODE evaluations, stage values read back)
+template <int MODEL>
+__global__ __launch_bounds__(128) void k_lin_tan(LinArgs a) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU, NZ = NX + NU;
+    const size_t tot = (size_t)a.B * a.N * NZ;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+        const int dir = t % NZ, k = (t / NZ) % a.N, b = t / ((size_t)NZ * a.N);
+        if (a.run && !a.run[b]) continue;
+        const size_t bk = (size_t)b * a.N + k;
+        const double *x = a.X + ((size_t)b * (a.N + 1) + k) * NX, *u = a.U + bk * NU;
+        double col[NX];
+        dyn::ddyn_tangent<MODEL>(x, u, a.stage + bk * 3 * NX, dir, col);
+        if (dir < NX) { double *A = a.A + bk * NX * NX; for (int i = 0; i < NX; i++) A[i * NX + dir] = col[i]; }
+        else { double *Bm = a.Bm + bk * NX * NU; for (int i = 0; i < NX; i++) Bm[i * NU + (dir - NX)] = col[i]; }
+    }
+}
 template <int MODEL>
 __global__ __launch_bounds__(128) void k_lin_jac(LinArgs a) {
     constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU, NZ = NX + NU;

@@ -197,12 +197,15 @@ class BatchedFastSLS:
         return dict(total=t[0], qp=t[1], sweep=t[2], other=t[3], jac=t[4])
 
     def kernel_timing(self):
-        """(total ms, launches) of the dominant kernel k_ne_fwd since the last call (HIP events on the handle's stream)."""
-        t = np.zeros(5)
+        """(total ms, launches) of the dominant QP kernel since the last call (HIP events on the handle's stream; needs opts.time_kernels = 1);
+        the device counters of the work those launches did land in attributes."""
+        t = np.zeros(8)
         self.lib.slsqp_kernel_timing(self.h, _ptr(t))
-        self.mx_retries = int(t[2])
-        self.fwd_instance_sweeps = int(t[3])   # instance forward sweeps those launches did
-        self.fwd_factor_sweeps = int(t[4])     # ... of which factorising      # instances re-solved in fp64 after a mixed-precision attempt (opts.precision = 1)
+        self.mx_retries = int(t[2])            # instances re-solved in fp64 after a mixed-precision attempt (opts.precision = 1)
+        self.fwd_instance_sweeps = int(t[3])   # instance forward sweeps (= backward sweeps)
+        self.fwd_factor_sweeps = int(t[4])     # ... of which factorising
+        self.factor_stages = int(t[5])         # stages factorised
+        self.qp_solves = int(t[6])             # QP solves started by k_qp_solve launches
         return t[0], int(t[1])
 
     def solve(self, x0, fetch=True):
@@ -408,11 +411,11 @@ class SlicedDeviceBatch:
     def kernel_timing(self):
         """Summed over the slices: (total ms of k_ne_fwd launches, launches, instance sweeps, fp64 re-solves)."""
         tot = [0.0, 0, 0, 0]
-        self.fwd_factor_sweeps = 0
+        self.fwd_factor_sweeps = self.factor_stages = self.qp_solves = 0
         for f in self.solvers:
             ms, n = f.kernel_timing()
             tot[0] += ms; tot[1] += n; tot[2] += f.fwd_instance_sweeps; tot[3] += f.mx_retries
-            self.fwd_factor_sweeps += f.fwd_factor_sweeps
+            self.fwd_factor_sweeps += f.fwd_factor_sweeps; self.factor_stages += f.factor_stages; self.qp_solves += f.qp_solves
         return tuple(tot)
 
     def close(self):

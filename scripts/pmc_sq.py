@@ -22,7 +22,7 @@ for k, v in acc.items():
     if bc > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
         d["mfma_busy_cycles_per_sq_busy_cycle"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / bc
     out[k] = d
-json.dump({"source": "rocprofv3 --pmc (one SQ pass), command: python3 bench.py --steps 2 --warmup 1 --no-cpu", "kernels": out}, open(dst, "w"), indent=1)
-for k in ("k_ne_fwd", "k_ne_bwd_phase", "k_sweep"):
+json.dump({"source": "rocprofv3 --pmc (one SQ pass), command: python3 bench.py --steps 5 --warmup 1 --no-cpu --no-secondary --slices 1", "kernels": out}, open(dst, "w"), indent=1)
+for k in ("k_qp_solve", "k_ne_fwd", "k_ne_bwd_phase", "k_sweep", "k_lin_jac"):
     if k in out:
         print(k, {a: (round(b, 4) if isinstance(b, float) and b < 10 else b) for a, b in out[k].items()})

@@ -1,8 +1,10 @@
-"""Turn the FETCH_SIZE / WRITE_SIZE passes of scripts/pmc.sh into profiles/r01/pmc_traffic.json (bytes per launch of every
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of scripts/pmc.sh into profiles/rNN/pmc_traffic.json (bytes per launch of every
 kernel).  FETCH_SIZE / WRITE_SIZE are reported in KiB (rocprofv3); on gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream
 (MI355X_MICROARCH.md, HBM section): both the raw and the doubled figure are stored."""
 import csv, glob, json, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
+build = sys.argv[3] if len(sys.argv) > 3 else "?"
+cmd = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 2 --warmup 1 --no-cpu --no-secondary"
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -14,8 +16,9 @@ for k, v in acc.items():
     nf, nw = max(1, len(calls[k]["FETCH_SIZE"])), max(1, len(calls[k]["WRITE_SIZE"]))
     fetch, write = v.get("FETCH_SIZE", 0.0) * 1024 / nf, v.get("WRITE_SIZE", 0.0) * 1024 / nw
     out[k] = {"launches": nf, "fetch_bytes_per_launch_raw": fetch, "fetch_bytes_per_launch_x2": 2 * fetch, "write_bytes_per_launch": write}
-res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), command: python bench.py --steps 2 --warmup 1 --no-cpu", "kernels": out}
-if "k_ne_fwd" in out:
-    res["k_ne_fwd_bytes_per_launch"] = out["k_ne_fwd"]["fetch_bytes_per_launch_x2"] + out["k_ne_fwd"]["write_bytes_per_launch"]
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), command: " + cmd, "build": build, "kernels": out}
+for kn in ("k_ne_fwd", "k_qp_solve", "k_sweep", "k_lin_jac"):
+    if kn in out:
+        res[kn + "_bytes_per_launch"] = out[kn]["fetch_bytes_per_launch_x2"] + out[kn]["write_bytes_per_launch"]
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps(res)[:1500])

@@ -1,0 +1,28 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): scripts/profile_round.sh <tag>
+# rocprofv3 kernel statistics and PMC passes of the bench command (default = 3 slices, and --slices 1), written under gpurun_out/<tag>/.
+# Counters are collected in their own passes (never combined with a trace domain); the program itself follows `--`.
+tag=${1:-prof}
+root=$GRAFT_REPO_ROOT
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+cmd="python3 $root/bench.py --steps 5 --warmup 1 --no-cpu --no-secondary"
+for sl in 3 1; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s$sl -o s$sl -- $cmd --slices $sl > $out/stats_s$sl.log 2>&1 || echo "stats pass (slices $sl) failed"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d $out/pmc_s$sl/$c -o p -- $cmd --slices $sl > $out/pmc_s${sl}_$c.log 2>&1 || echo "pmc $c (slices $sl) failed"
+  done
+done
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/pmc_sq -o p -- $cmd --slices 1 > $out/pmc_sq.log 2>&1 || echo "sq pass failed"
+cd $root
+for sl in 3 1; do
+  f=$(ls $out/stats_s$sl/*kernel_stats.csv $out/stats_s$sl/*/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && cp $f $out/kernel_stats_s$sl.csv
+  python3 scripts/pmc_traffic.py $out/pmc_s$sl $out/pmc_traffic_s$sl.json "$(git rev-parse --short HEAD 2>/dev/null || echo worktree)" "$cmd --slices $sl" > /dev/null
+done
+python3 scripts/pmc_sq.py $out/pmc_sq $out/pmc_sq.json > $out/pmc_sq_summary.txt 2>&1
+# keep what is copied back small: the raw per-dispatch csv files stay on the box
+rm -rf $out/stats_s3 $out/stats_s1 $out/pmc_s3 $out/pmc_s1 $out/pmc_sq
+ls -la $out
+head -12 $out/kernel_stats_s3.csv

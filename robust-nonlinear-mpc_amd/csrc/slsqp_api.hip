@@ -50,6 +50,7 @@ struct slsqp_handle {
     int *scp_active, *scp_success, *scp_iters, *pending_reset, *scp_upd; double *scp_dmax;
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
     int *retry; int mx_retry, mx_retry_total;
+    double *Kc, *Aclc;          // (B,N,nu,nx), (B,N,nx,nx): K_k and A_k + B_k K_k of the shared Riccati recursion (k_sweep_ric1 -> k_sweep_prop)
     double *lin_stage;          // (B,N,3,nx) intermediate RK4 stage points of the linearisation (k_lin_val -> k_lin_tan)
     double call_id;             // counts fast-SLS calls (validity of the interior-point iterate copies, QpArgs::call_id)
     int *qpstat;                // (B,2,8) per-QP statistics, see QpArgs::qpstat
@@ -133,7 +134,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(h->owned, &h->nom_st, B * 12); rc |= dalloc(h->owned, &h->nom_need_lin, B); rc |= dalloc(h->owned, &h->nom_status, B); rc |= dalloc(h->owned, &h->nom_iters, B);
     rc |= dalloc(h->owned, &h->mapA, (size_t)N * nx * nx); rc |= dalloc(h->owned, &h->mapB, (size_t)N * nx * nu);
     rc |= dalloc(h->owned, &h->inst_launches, (size_t)4); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
-    rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
+    rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->Kc, B * N * nu * nx); rc |= dalloc(h->owned, &h->Aclc, B * N * nx * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
     h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { free_all(h->owned); hipStreamDestroy(h->st); delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
@@ -453,10 +454,26 @@ static int launch_sweep_t(slsqp_handle *h, const SweepArgs &a) {
     HIPCHK(hipGetLastError());
     return 0;
 }
-static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, const double *eta_f, double eps) {
+template <int NX, int NU>
+static int launch_sweep_shared_t(slsqp_handle *h, const SweepArgs &a) {
+    SweepSharedArgs aa{a, h->Kc, h->Aclc};
+    const size_t lds_ric = sizeof(double) * sweep_lds_doubles<NX, NU>(), lds_prop = sizeof(double) * sweep_prop_lds_doubles<NX, NU>();
+    hipLaunchKernelGGL((k_sweep_ric1<NX, NU>), dim3(h->B), dim3(64), lds_ric, h->st, aa);
+    hipLaunchKernelGGL((k_sweep_prop<NX, NU>), dim3(h->B * (h->d.N + 1)), dim3(64), lds_prop, h->st, aa);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// shared_cols: every column's eta is the same (first fast-SLS iteration after initialize_backoff): one Riccati recursion per instance
+static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, const double *eta_f, double eps, bool shared_cols = false) {
     SweepArgs a;
     a.B = h->B; a.N = h->d.N; a.NW = h->d.nw; a.A = h->A; a.Bm = h->Bm; a.E = h->E; a.E_per_instance = 0; a.eta = eta; a.eta_f = eta_f;
     a.run = run; a.cst = costs_of(h); a.K = h->K; a.beta = h->beta; a.beta_f = h->beta_f; a.ct_part = h->ct_part; a.eps = eps;
+    static const bool allow_shared = getenv("SLSQP_SWEEP_SHARED") ? atoi(getenv("SLSQP_SWEEP_SHARED")) != 0 : true;
+    if (shared_cols && allow_shared) {
+        if (h->d.nx == 4) return launch_sweep_shared_t<4, 1>(h, a);
+        if (h->d.nx == 13) return launch_sweep_shared_t<13, 4>(h, a);
+        return launch_sweep_shared_t<17, 4>(h, a);
+    }
     if (h->d.nx == 4) return launch_sweep_t<4, 1>(h, a);
     if (h->d.nx == 13) return launch_sweep_t<13, 4>(h, a);
     return launch_sweep_t<17, 4>(h, a);
@@ -509,7 +526,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), h->st));
         hipLaunchKernelGGL(k_post_conv, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->conv, h->alive, h->mask, h->success, h->itnum, h->counter, h->stale);
         HIPCHK(hipEventRecord(h->ev[3], h->st));
-        if (launch_sweep(h, h->mask, h->eta, h->eta_f, o.eps_backoff)) return -1;
+        if (launch_sweep(h, h->mask, h->eta, h->eta_f, o.eps_backoff, /* beta == eps for every column right after initialize_backoff */ i == 0)) return -1;
         HIPCHK(hipEventRecord(h->ev[4], h->st));
         TightenArgs ta{B, d.N, d.nx, d.nu, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1, h->ct_part, h->cost_tube};
         hipLaunchKernelGGL(k_tighten, dim3(B), dim3(128), 0, h->st, ta);

@@ -1458,6 +1458,239 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// The sweep of the FIRST fast-SLS iteration of a solve.  initialize_backoff (fast_SLS_jit.py:444-454) has just reset every beta[k,j] to eps, so
+// evaluate_dual_eta (:475-487) gives eta[k,j] = mu_k / (2 sqrt(eps)) for every column j <= k and eta_f[j] = mu_f / (2 sqrt(eps)) for every j: the
+// cost blocks of the N+1 Riccati recursions of _backward_solve_numba (:65-84) are the same, hence S[k,j] = S[k], K[k,j] = K[k] and
+// A_k + B_k K_k for all j <= k.  One wave per instance runs that recursion once (k_sweep_ric1: 20 stages instead of 210) and leaves K_k and
+// A_k + B_k K_k in a compact scratch; one wave per (instance, column) then only propagates Phi and takes the row norms (k_sweep_prop).  Same
+// arithmetic in the same order as k_sweep, which remains for the later iterations of a solve (beta, hence eta, then differ from column to column).
+// In the rocket script's setting (one fast-SLS step per MPC step) every sweep is a first one.
+// ------------------------------------------------------------------------------------------------
+struct SweepSharedArgs {
+    SweepArgs s;
+    double *Kc, *Aclc;         // scratch (B,N,NU,NX), (B,N,NX,NX)
+};
+template <int NX, int NU>
+__global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep_ric1(SweepSharedArgs aa) {
+    const SweepArgs &a = aa.s;
+    using L = Lay<NX, NU>;
+    constexpr int NZ = L::NZ, NI = L::NI, NIF = L::NIF;
+    const int N = a.N, lane = threadIdx.x, b = blockIdx.x, j = 0;
+    if (b >= a.B) return;
+    if (a.run && !a.run[b]) return;
+    extern __shared__ double sm[];
+    double *p = sm;
+    double *sA = p; p += NX * NX; double *sS = p; p += NX * NX; double *sYm = p; p += NX * NX;
+    double *sAcl = sA, *sSn = sS;
+    double *sB = p; p += NX * NU; double *sX = p; p += NX * NU; double *sF = p; p += NX * NU; double *sK = p; p += NX * NU;
+    p += NU * NX; double *sH = p; p += NU * NU; double *sC = p; p += NZ;
+    const double *gA = a.A + (size_t)b * N * NX * NX, *gB = a.Bm + (size_t)b * N * NX * NU;
+    const double *eta = a.eta + (size_t)b * N * N * NI, *eta_f = a.eta_f + (size_t)b * (N + 1) * NIF;
+    double *gKc = aa.Kc + (size_t)b * N * NU * NX, *gAc = aa.Aclc + (size_t)b * N * NX * NX;
+#pragma unroll
+    for (int o = lane; o < NX * NX; o += 64) {
+        const int i = o / NX, jj = o % NX;
+        sS[o] = (i == jj) ? eta_f[j * NIF + i] + eta_f[j * NIF + NX + i] + a.cst.Qregfd[i] : 0.0;
+    }
+    wla::wsync();
+    constexpr int RA = (NX * NX + 63) / 64, RB = (NX * NU + 63) / 64;
+    double rA[RA], rB[RB], rC = 0.0;
+    const int lz = min(lane, NZ - 1);
+    const double regd = (lz < NX) ? a.cst.Qregd[lz] : a.cst.Rregd[lz - NX];
+    auto fetch = [&](int k) {
+        const double *Ak = gA + (size_t)k * NX * NX, *Bk = gB + (size_t)k * NX * NU;
+#pragma unroll
+        for (int r = 0; r < RA; r++) rA[r] = Ak[min(r * 64 + lane, NX * NX - 1)];
+#pragma unroll
+        for (int r = 0; r < RB; r++) rB[r] = Bk[min(r * 64 + lane, NX * NU - 1)];
+        const double *e = eta + ((size_t)k * N + j) * NI;
+        rC = e[lz] + e[NZ + lz] + regd;
+    };
+    fetch(N - 1);
+    for (int k = N - 1; k >= 0; k--) {
+#pragma unroll
+        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < NX * NX) sA[o] = rA[r]; }
+#pragma unroll
+        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) sB[o] = rB[r]; }
+        if (lane < NZ) sC[lane] = rC;
+        wla::wsync();
+        if (k - 1 >= 0) fetch(k - 1);
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NU, NX, NX, true, false>(sB, NU, sS, NX, sX, NX, lane);
+        else
+#endif
+        wla::gemm_blk<NU, NX, NX, true, false, 1, 2, false>(sB, NU, sS, NX, sX, NX, 1.0, lane);   // x = B' S   (NU x NX)
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NX, NX, NX, true, false>(sA, NX, sS, NX, sYm, NX, lane);
+        else
+#endif
+        wla::gemm_blk<NX, NX, NX, true, false, 3, 2, false>(sA, NX, sS, NX, sYm, NX, 1.0, lane);  // y = A' S   (NX x NX)
+        wla::wsync();
+        {
+            constexpr int NH = NU * NU;
+            const int g3 = lane / NH, o = lane - g3 * NH, hi = o / NU, hj = o % NU;
+            double hs = 0.0;
+            if (g3 < 3) {
+#pragma unroll
+                for (int q = 0; q < (NX + 2) / 3; q++) { const int kk = 3 * q + g3; if (kk < NX) hs = fma(sX[hi * NX + kk], sB[kk * NU + hj], hs); }
+            }
+            hs = hs + __shfl(hs, lane + NH) + __shfl(hs, lane + 2 * NH);
+            if (lane < NH) sH[lane] = hs;
+        }
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NU, NX, NX, false, false>(sX, NX, sA, NX, sF, NX, lane);
+        else
+#endif
+        wla::gemm_blk<NU, NX, NX, false, false, 1, 2, false>(sX, NX, sA, NX, sF, NX, 1.0, lane);  // F = x A
+        wla::wsync();
+        if (lane < NU) sH[lane * NU + lane] += sC[NX + lane];
+        wla::wsync();
+        if (lane < NX) {
+            double f[NU];
+#pragma unroll
+            for (int u = 0; u < NU; u++) f[u] = sF[u * NX + lane];
+            wla::spd_solve_small<NU>(sH, NU, f);
+#pragma unroll
+            for (int u = 0; u < NU; u++) sK[u * NX + lane] = -f[u];
+        }
+        wla::wsync();
+        double *Kg = gKc + (size_t)k * NU * NX;
+#pragma unroll
+        for (int o = lane; o < NU * NX; o += 64) Kg[o] = sK[o];
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NX, NX, NU, false, false, true>(sB, NU, sK, NX, sAcl, NX, lane, sA, NX);
+        else
+#endif
+#pragma unroll
+        for (int o = lane; o < NX * NX; o += 64) {
+            const int i = o / NX, jj = o % NX;
+            double s = sA[o];
+#pragma unroll
+            for (int u = 0; u < NU; u++) s = fma(sB[i * NU + u], sK[u * NX + jj], s);
+            sAcl[o] = s;
+        }
+        wla::wsync();
+        double *Ag = gAc + (size_t)k * NX * NX;
+#pragma unroll
+        for (int o = lane; o < NX * NX; o += 64) Ag[o] = sAcl[o];
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NX, NX, NX, false, false>(sYm, NX, sAcl, NX, sSn, NX, lane);
+        else
+#endif
+        wla::gemm_blk<NX, NX, NX, false, false, 3, 2, false>(sYm, NX, sAcl, NX, sSn, NX, 1.0, lane);  // y (A + B K)
+        wla::wsync();
+#pragma unroll
+        for (int o = lane; o < NX * NX; o += 64) {
+            const int i = o / NX, jj = o % NX;
+            if (i >= jj) {
+                const double v = 0.5 * (sSn[o] + sSn[jj * NX + i]) + ((i == jj) ? sC[i] : 0.0);
+                sS[o] = v; sS[jj * NX + i] = v;
+            }
+        }
+        wla::wsync();
+    }
+}
+
+template <int NX, int NU>
+__host__ __device__ constexpr int sweep_prop_lds_doubles() { return 3 * NX * NX + 2 * NX * NU + 8; }
+
+template <int NX, int NU>
+__global__ __launch_bounds__(64, 4) void k_sweep_prop(SweepSharedArgs aa) {
+    const SweepArgs &a = aa.s;
+    using L = Lay<NX, NU>;
+    constexpr int NZ = L::NZ, NI = L::NI, NIF = L::NIF, NW = NX;
+    const int N = a.N, lane = threadIdx.x;
+    const int ncol = N + 1;
+    int b, j;
+    {
+        const int bid = blockIdx.x;
+        const int Bfull = (a.B / 8) * 8;
+        if (bid < Bfull * ncol) {
+            const int xcd = bid % 8, slot = bid / 8;
+            b = (slot / ncol) * 8 + xcd; j = slot % ncol;
+        } else {
+            const int r = bid - Bfull * ncol;
+            b = Bfull + r / ncol; j = r % ncol;
+        }
+    }
+    if (b >= a.B) return;
+    if (a.run && !a.run[b]) return;
+    extern __shared__ double sm[];
+    double *p = sm;
+    double *sAcl = p; p += NX * NX; double *sPhi = p; p += NX * NX; double *sPhi2 = p; p += NX * NX;
+    double *sK = p; p += NX * NU; double *sPu = p; p += NU * NW;
+    const double *gKc = aa.Kc + (size_t)b * N * NU * NX, *gAc = aa.Aclc + (size_t)b * N * NX * NX;
+    double *gK = a.K + (size_t)b * N * (N + 1) * NU * NX;
+    double *beta = a.beta + (size_t)b * N * N * NI, *beta_f = a.beta_f + (size_t)b * (N + 1) * NIF;
+    const double *Eg = a.E + (a.E_per_instance ? (size_t)b * (N + 1) * NX * NW : 0) + (size_t)j * NX * NW;
+#pragma unroll
+    for (int o = lane; o < NX * NW; o += 64) sPhi[o] = Eg[o];
+    wla::wsync();
+    double *Pc = sPhi, *Pn = sPhi2;
+    constexpr int RA = (NX * NX + 63) / 64, RB = (NX * NU + 63) / 64;
+    double rA[RA], rK[RB];
+    double ctube = 0.0;
+    auto fetch2 = [&](int k) {
+        const double *Ak = gAc + (size_t)k * NX * NX, *Kk = gKc + (size_t)k * NU * NX;
+#pragma unroll
+        for (int r = 0; r < RA; r++) rA[r] = Ak[min(r * 64 + lane, NX * NX - 1)];
+#pragma unroll
+        for (int r = 0; r < RB; r++) rK[r] = Kk[min(r * 64 + lane, NX * NU - 1)];
+    };
+    if (j < N) fetch2(j);
+    for (int k = j; k < N; k++) {
+        double *Kg = gK + ((size_t)k * (N + 1) + j) * NU * NX;
+#pragma unroll
+        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < NX * NX) sAcl[o] = rA[r]; }
+#pragma unroll
+        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) { sK[o] = rK[r]; Kg[o] = rK[r]; } }   // K[k,j] = K_k of the result
+        wla::wsync();
+        if (k + 1 < N) fetch2(k + 1);
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NU, NW, NX, false, false>(sK, NX, Pc, NW, sPu, NW, lane);
+        else
+#endif
+        wla::gemm_blk<NU, NW, NX, false, false, 1, 2, false>(sK, NX, Pc, NW, sPu, NW, 1.0, lane);  // Phi_u = K Phi_x
+        wla::wsync();
+        {
+            const int g3 = lane / NZ, rw = lane - g3 * NZ;
+            const double *row = (rw < NX) ? Pc + rw * NW : sPu + (rw - NX) * NW;
+            double s = 0.0;
+            if (g3 < 3) {
+#pragma unroll
+                for (int q = 0; q < (NW + 2) / 3; q++) { const int w = 3 * q + g3; if (w < NW) s = fma(row[w], row[w], s); }
+            }
+            s = s + __shfl(s, lane + NZ) + __shfl(s, lane + 2 * NZ);
+            if (lane < NZ) {
+                const double wr = (lane < NX) ? a.cst.Qregd[lane] : a.cst.Rregd[lane - NX];
+                ctube = fma(wr * wr, s, ctube);
+                s = fmax(s, a.eps);
+                double *bo = beta + ((size_t)k * N + j) * NI;
+                bo[lane] = s; bo[NZ + lane] = s;
+            }
+        }
+#if SWEEP_MFMA
+        if constexpr (NX >= 13) wla::gemm_mfma<NX, NW, NX, false, false>(sAcl, NX, Pc, NW, Pn, NW, lane);        // Phi_{k+1} = Acl Phi_k
+        else
+#endif
+        wla::gemm_blk<NX, NW, NX, false, false, 3, 2, false>(sAcl, NX, Pc, NW, Pn, NW, 1.0, lane);
+        wla::wsync();
+        double *t = Pc; Pc = Pn; Pn = t;
+    }
+    if (lane < NX) {
+        const double *row = Pc + lane * NW;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) s = fma(row[w], row[w], s);
+        ctube = fma(a.cst.Qregfd[lane] * a.cst.Qregfd[lane], s, ctube);
+        s = fmax(s, a.eps);
+        beta_f[j * NIF + lane] = s; beta_f[j * NIF + NX + lane] = s;
+    }
+    ctube = wla::wave_sum(ctube);
+    if (lane == 0 && a.ct_part) a.ct_part[(size_t)b * (N + 1) + j] = ctube;
+}
+
+// ------------------------------------------------------------------------------------------------
 // backoff sums + tightened bounds (fast_SLS_jit.py:173-186, 556-569) ; one workgroup per instance
 // ------------------------------------------------------------------------------------------------
 struct TightenArgs {

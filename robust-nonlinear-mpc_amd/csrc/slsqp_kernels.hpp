@@ -106,13 +106,14 @@ template <int NX, int NU>
 __host__ __device__ constexpr int qp_lds_doubles(int) { return QpLds<NX, NU>::TOTAL; }
 
 // workspace arrays per instance (doubles): 12 n-vectors + 3 (N*NX)-vectors of the solver, then the copy of an interior-point iterate
-// (6 n-vectors + 1 (N*NX)-vector: z, s_u, s_l, lambda_u, lambda_l, E'nu, nu), then the certified active set of the call's first QP (1 n-vector)
-__host__ __device__ inline size_t qp_ws_doubles(int n, int N, int NX) { return (size_t)19 * n + (size_t)4 * N * NX; }
+// (6 n-vectors + 1 (N*NX)-vector: z, s_u, s_l, lambda_u, lambda_l, E'nu, nu), then the certified active set of the call's first QP (1 n-vector) and u of the last forward sweep (1 (N*NX)-vector)
+__host__ __device__ inline size_t qp_ws_doubles(int n, int N, int NX) { return (size_t)19 * n + (size_t)5 * N * NX; }
 
 template <int NX, int NU>
 struct NeG {   // global-memory operands of the sweeps (this instance)
     const double *A, *Bm, *ub, *lb;
     double *Linv, *PI, *V, *G, *W;
+    double *UF;      // u_k of the last forward sweep (fp64 kernels; the backward sweep turns them into nu_k in W)
     int N;
 };
 
@@ -127,9 +128,12 @@ struct NeG {   // global-memory operands of the sweeps (this instance)
 #endif
 template <int NX, int NU>
 __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool factor_all, double eflag, double delta, int lane, long long *dbg = nullptr,
-                                          double *bmax_out = nullptr, int k0 = 0) {
+                                          double *bmax_out = nullptr, int k0 = 0, int ks = 0) {
     // k0 > 0 (active-set rounds): the stages before k0 keep the factorisation of the previous round -- their D_k depend on Pi of the stages
-    // <= k + 1 only, and no entry of Pi changed there -- so their inverses are read back from the scratch like in a solve-only sweep
+    // <= k + 1 only, and no entry of Pi changed there -- so their inverses are read back from the scratch like in a solve-only sweep.
+    // ks > 0 (<= k0): the sweep starts at stage ks.  The right-hand side of an active-set round differs from the previous round's only where the
+    // set changed (v = -pi q on free elements, the bound on fixed ones), i.e. from stage k0 on, so u_0 .. u_{ks-1} of the previous sweep (kept in
+    // UF) still hold and only u_{ks-1} and Dinv_{ks-1} are read back.
     double bmax = 0.0;
 #ifdef NE_STAMP
     long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
@@ -157,8 +161,14 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
         rPi = g.PI[k * NZ + ls]; rV = g.V[k * NZ + ls];
         if (eflag != 0.0) rE = 0.5 * (g.ub[k * SR + lx] + g.lb[k * SR + lx]);
     };
-    prefetch(0);
-    for (int k = 0; k < g.N; k++) {
+    if (ks > 0) {
+        const double *Lg = g.Linv + (size_t)(ks - 1) * MM;
+#pragma unroll
+        for (int o = lane; o < MM; o += 64) Lprev[o] = Lg[o];
+        if (lane < NX) sWp[lane] = g.UF[(ks - 1) * NX + lane];
+    }
+    prefetch(ks);
+    for (int k = ks; k < g.N; k++) {
         const bool factor = factor_all && k >= k0;
 #pragma unroll
         for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < MM) sA[o] = rA[r]; }
@@ -212,7 +222,7 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
         wla::wsync();
         const double w = wla::matvec_split3<NX, NX, false>(Lcur, NX, sT2, lane);   // u_k = Dinv_k t_k
         wla::wsync();
-        if (lane < NX) { sWp[lane] = w; g.W[k * NX + lane] = w; }
+        if (lane < NX) { sWp[lane] = w; g.UF[k * NX + lane] = w; }
         double *t = Lcur; Lcur = Lprev; Lprev = t;
         wla::wsync();
         STAMP(6);
@@ -248,7 +258,7 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
 #pragma unroll
         for (int q = 0; q < RB; q++) r.B[q] = Bk[min(q * 64 + lane, NX * NU - 1)];
         const int lx = min(lane, NX - 1);
-        r.Pi = g.PI[(k + 1) * NZ + lx]; r.W = g.W[k * NX + lx];
+        r.Pi = g.PI[(k + 1) * NZ + lx]; r.W = g.UF[k * NX + lx];
     };
     auto stage = [&](int k, StageRegs &r) {
 #pragma unroll
@@ -493,9 +503,10 @@ struct QpState {   // per instance, 36 doubles
                                                   // cold_as 1: that attempt was made; nviol: violated bounds seen by the previous round;
                                                   // path: how the solve ended up where it is (qp_stats[7])
     unsigned long long seth[4];                   // hashes of the last active sets of the current attempt (a repeat = the iteration cycles)
-    double kmin, fact_call, act1_ok, pad5;        // first stage whose block D_k the next P_POL0 factorisation must recompute (see ne_forward k0);
+    double kmin, fact_call, act1_ok, uf_valid;    // first stage whose block D_k the next P_POL0 factorisation must recompute (see ne_forward k0);
                                                   // fact_call: call whose last certified solve left its factorisation (for the set in ACT) in the
-                                                  // scratch; act1_ok: ACT1 holds a certified set
+                                                  // scratch; act1_ok: ACT1 holds a certified set; uf_valid: the last forward sweep solved the current attempt's
+                                                  // un-refined system, so UF's leading u_k carry over to the next round (ne_forward ks)
 };
 
 template <int NX, int NU>
@@ -507,20 +518,21 @@ __device__ __forceinline__ NeG<NX, NU> make_neg(const QpArgs &a, int b) {
     g.A = a.A + (size_t)b * N * NX * NX; g.Bm = a.Bm + (size_t)b * N * NX * NU;
     g.ub = a.ubg + (size_t)b * mb; g.lb = a.lbg + (size_t)b * mb;
     g.Linv = a.Linv + (size_t)b * N * NX * NX; g.PI = ws + 8 * (size_t)n; g.V = ws + 9 * (size_t)n; g.G = ws + 10 * (size_t)n;
-    g.W = ws + 12 * (size_t)n; g.N = N;
+    g.W = ws + 12 * (size_t)n; g.UF = ws + 19 * (size_t)n + 4 * (size_t)N * NX; g.N = N;
     return g;
 }
 
 // what the forward sweep of a tick does, from the instance's phase: factorise? right-hand side with the dynamics offsets? regularisation; first
 // stage to re-factorise.  The active-set rounds regularise with 1e-10 (also the P_INIT solve that serves as their round 0, so that the next
 // round can keep its leading blocks).
-struct FwdPlan { bool factor; double eflag, delta; int k0; };
-__device__ __forceinline__ FwdPlan fwd_plan(const QpState *st, int phase) {
+struct FwdPlan { bool factor; double eflag, delta; int k0, ks; };
+__device__ __forceinline__ FwdPlan fwd_plan(const QpState *st, int phase, int N) {
     FwdPlan p;
     p.factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
     p.eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
     p.delta = (phase == P_POL0 || (phase == P_INIT && st->mode == 0.0)) ? 1e-10 : 0.0;
     p.k0 = (phase == P_POL0) ? (int)st->kmin : 0;
+    p.ks = (phase == P_POL0 && st->uf_valid != 0.0 && p.k0 < N) ? p.k0 : 0;   // (kmin = N: first tick of a QP that inherits its factorisation -- its right-hand side is new)
     return p;
 }
 
@@ -532,14 +544,14 @@ __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
     const int phase = (int)st->phase;
     if (phase == P_DONE) return;
     extern __shared__ double sm[];
-    const FwdPlan fp = fwd_plan(st, phase);
+    const FwdPlan fp = fwd_plan(st, phase, a.N);
     const bool factor = fp.factor;
     double bmax = 0.0;
     const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane,
 #ifdef NE_STAMP_BWD
-                                     nullptr, &bmax, fp.k0);
+                                     nullptr, &bmax, fp.k0, fp.ks);
 #else
-                                     (long long *)(a.kkt + (size_t)b * 8), &bmax, fp.k0);
+                                     (long long *)(a.kkt + (size_t)b * 8), &bmax, fp.k0, fp.ks);
 #endif
     // in the refinement solves the right-hand side is E zn - e (+ a vanishing term): the dynamics residual of the polished point
     if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
@@ -609,11 +621,11 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 const double zp = (e < NX) ? a.x0val[(size_t)b * NX + e] : prev[e];
                 const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zp);
                 const double pi = (el.fr && ac == 0.0) ? wla::fast_rcp(el.pd) : 0.0;
-                ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
+                ACT[e] = ac; PI[e] = pi; V[e] = (pi != 0.0) ? -pi * el.q : z0;
             } else {
                 const double z0 = (e < NX) ? a.x0val[(size_t)b * NX + e] : 0.0;   // rhs of P_INIT: v = z0 - Pi (P z0 + q), z0 = [x0;0]
                 const double pi = el.fr ? wla::fast_rcp(el.pd) : 0.0;
-                PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q); Z[e] = z0;
+                PI[e] = pi; V[e] = (pi != 0.0) ? -pi * el.q : z0; Z[e] = z0;
             }
         }
         qscale = fmax(1.0, wla::wave_max(qscale));
@@ -625,7 +637,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1; s0.ticks = 0; s0.fticks = 0; s0.tight = 0; s0.pad = 0;
             s0.snap_call = stp->snap_call; s0.snap_mu = stp->snap_mu; s0.snap_used = 0; s0.pad2 = 0;
             s0.mode = a.as_first ? 0.0 : 1.0; s0.cold_as = 0; s0.nviol = 0; s0.path = warm ? 10.0 : 0.0;
-            s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.pad5 = 0;
+            s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.uf_valid = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
             if (status == ST_INIT) atomicAdd(a.n_active, 1);
@@ -841,7 +853,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 const double zn = CU[e], ac = G[e];
                 const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : zn);
                 const double pi = (el.fr && ac == 0.0) ? wla::fast_rcp(el.pd) : 0.0;
-                ACT[e] = ac; PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
+                ACT[e] = ac; PI[e] = pi; V[e] = (pi != 0.0) ? -pi * el.q : z0;
             }
         };
         bool again = false, give_up = false;
@@ -857,7 +869,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             // violated bounds -- is left to the interior point at once
             if (s.warm > 0.0 && (nv > (double)a.as_max_viol || (s.pol_round > 0.0 && nv > 2.0 * s.nviol + 8.0))) { again = false; give_up = true; }
             s.nviol = nv;
-            if (again) { s.pol_round += 1.0; apply_set(); }
+            if (again) { s.pol_round += 1.0; apply_set(); s.uf_valid = 1.0; }      // the sweep just consumed solved the un-refined system of this attempt
         } else if (phase == P_POL0 && s.warm > 0.0) give_up = true;      // out of rounds (or a pivot failed): do not refine a set known to be wrong
         if (again) {
             phase = P_POL0;
@@ -900,7 +912,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 unsigned long long hsh = 0ULL;
                 plan_set(ptol, nv, hsh);
                 if (s.warm > 0.0 && seen_before(hsh)) fall_back = true;
-                else { s.pol_round += 1.0; s.nviol = nv; apply_set(); phase = P_POL0; }
+                else { s.pol_round += 1.0; s.nviol = nv; apply_set(); phase = P_POL0; s.uf_valid = 0.0; }   // the last sweep was the refinement's
             } else if (s.warm > 0.0) {
                 fall_back = true;      // warm / cold active-set attempt failed
             } else if (s.tight == 0.0 && a.eps > 1e-9 && status == 4) {
@@ -917,7 +929,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         // the interior point takes over: from the iterate an earlier QP of this call left behind when there is one (no P_INIT solve then),
         // from its cold start otherwise
         const bool try_cold_as = a.as_first && s.cold_as == 0.0 && s.warm == 1.0;
-        s.pol_round = 0.0; s.pol_fail = 0.0; s.seth[0] = s.seth[1] = s.seth[2] = s.seth[3] = 0ULL;
+        s.pol_round = 0.0; s.pol_fail = 0.0; s.seth[0] = s.seth[1] = s.seth[2] = s.seth[3] = 0ULL; s.uf_valid = 0.0;
         if (!try_cold_as && a.snap_use && s.snap_call == a.call_id && a.call_id != 0.0) {
             s.warm = -1.0; s.path = (s.path >= 10.0 ? 10.0 : 0.0) + 2.0;
             restore_iterate(s.snap_mu);
@@ -932,7 +944,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
                 const double z0 = (e < NX) ? a.x0val[(size_t)b * NX + e] : 0.0;
                 const double pi = el.fr ? wla::fast_rcp(el.pd) : 0.0;
-                PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q); Z[e] = z0;
+                PI[e] = pi; V[e] = (pi != 0.0) ? -pi * el.q : z0; Z[e] = z0;
             }
             phase = P_INIT;
         }
@@ -977,9 +989,9 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 const bool aL = el.fl && !aU && (-lam > z - el.lo);
                 const double z0 = aU ? el.hi : (aL ? el.lo : z);
                 const double pi = (el.fr && !aU && !aL) ? wla::fast_rcp(el.pd) : 0.0;
-                ACT[e] = aU ? 1.0 : (aL ? -1.0 : 0.0); PI[e] = pi; V[e] = z0 - pi * (el.pd * z0 + el.q);
+                ACT[e] = aU ? 1.0 : (aL ? -1.0 : 0.0); PI[e] = pi; V[e] = (pi != 0.0) ? -pi * el.q : z0;
             }
-            phase = P_POL0; s.kmin = 0.0;
+            phase = P_POL0; s.kmin = 0.0; s.uf_valid = 0.0;
         } else if (it >= a.max_iter) { status = 1; phase = P_DONE; }
         else phase = P_PRED;
     }
@@ -1094,10 +1106,10 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
         QpState *st = (QpState *)a.state + b;
         const int phase = (int)st->phase;
         if (phase == P_DONE) break;
-        const FwdPlan fp = fwd_plan(st, phase);
+        const FwdPlan fp = fwd_plan(st, phase, a.N);
         const bool factor = fp.factor;
         double bmax = 0.0;
-        const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, nullptr, &bmax, fp.k0);
+        const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, nullptr, &bmax, fp.k0, fp.ks);
         if (lane == 0) {
             if (phase == P_POL1 || phase == P_POL2) st->pbox = bmax;
             st->ticks += 1.0;
@@ -1128,7 +1140,7 @@ __global__ __launch_bounds__(64, QP_MX_WAVES_PER_SIMD) void k_ne_fwd_mx(QpArgs a
     const int phase = (int)st->phase;
     if (phase == P_DONE) return;
     extern __shared__ double sm[];
-    const FwdPlan fp = fwd_plan(st, phase);
+    const FwdPlan fp = fwd_plan(st, phase, a.N);
     const bool factor = fp.factor;
     double bmax = 0.0;
     const int f = ne_forward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, &bmax, fp.k0);

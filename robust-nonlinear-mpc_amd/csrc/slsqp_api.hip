@@ -61,6 +61,8 @@ struct slsqp_handle {
     double *stage;     // staging buffer for host<->device transfers
     size_t stage_bytes;
     bool have_costs, have_cons, have_dyn;
+    bool general_G;             // G, Gf are not [I;-I]: only the sweep-level boundary (slsqp_sweep) is available
+    double *Gd, *Gfd;           // device copies of G (ni, nx+nu) and Gf (ni_f, nx) when general_G
     hipEvent_t ev[8];
     std::vector<hipEvent_t> kev;   // event pairs around every k_ne_fwd launch of the last QP solve (only with opts.time_kernels)
     int n_kev; bool time_kernels;
@@ -90,7 +92,26 @@ static int dalloc(std::vector<void *> &owned, T **p, size_t count) {
 }
 static void free_all(std::vector<void *> &owned) { for (void *p : owned) if (p) hipFree(p); owned.clear(); }
 
-static bool supported_dims(int nx, int nu) { return (nx == 4 && nu == 1) || (nx == 13 && nu == 4) || (nx == 17 && nu == 4); }
+// (nx, nu) pairs the QP / sweep kernels are instantiated for: the reference's three plants, plus whatever the build adds with
+//   -DSLSQP_EXTRA_DIMS="X(6,2) X(9,3)"      (limits of the single-wave kernels: nx <= 17, nu <= 4, nx + nu <= 21)
+// The plant-specific entry points (slsqp_set_model / slsqp_linearize / slsqp_cl_*) exist for the three plants only.
+#ifndef SLSQP_EXTRA_DIMS
+#define SLSQP_EXTRA_DIMS
+#endif
+#define SLSQP_DIM_LIST X(4, 1) X(13, 4) X(17, 4) SLSQP_EXTRA_DIMS
+static bool supported_dims(int nx, int nu) {
+#define X(NX_, NU_) if (nx == NX_ && nu == NU_) return true;
+    SLSQP_DIM_LIST
+#undef X
+    return false;
+}
+static std::string dims_list() {
+    std::string r;
+#define X(NX_, NU_) r += " (" #NX_ "," #NU_ ")";
+    SLSQP_DIM_LIST
+#undef X
+    return r;
+}
 
 extern "C" int slsqp_qp_nnz(const slsqp_dims *d, int *n, int *m, int *nnzP, int *nnzA) {
     const int nz = d->nx + d->nu;
@@ -102,8 +123,8 @@ extern "C" int slsqp_qp_nnz(const slsqp_dims *d, int *n, int *m, int *nnzP, int 
 }
 
 extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device) {
-    if (!supported_dims(d->nx, d->nu)) { fail("unsupported (nx,nu): kernels are instantiated for (4,1) (13,4) (17,4)"); return nullptr; }
-    if (d->ni != 2 * (d->nx + d->nu) || d->ni_f != 2 * d->nx) { fail("ni/ni_f must be 2(nx+nu)/2nx (box constraints G=[I;-I])"); return nullptr; }
+    if (!supported_dims(d->nx, d->nu)) { fail("unsupported (nx,nu): this build instantiates the kernels for" + dims_list() + " (add pairs with -DSLSQP_EXTRA_DIMS)"); return nullptr; }
+    if (d->ni < 1 || d->ni_f < 1 || d->ni > 4096 || d->ni_f > 4096) { fail("need 1 <= ni, ni_f <= 4096"); return nullptr; }
     if (d->nw != d->nx) { fail("nw must equal nx"); return nullptr; }
     if (d->N < 1 || d->N > 32 || batch < 1) { fail("need 1 <= N <= 32 and batch >= 1"); return nullptr; }
     int ndev = 0;
@@ -134,7 +155,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(h->owned, &h->nom_st, B * 12); rc |= dalloc(h->owned, &h->nom_need_lin, B); rc |= dalloc(h->owned, &h->nom_status, B); rc |= dalloc(h->owned, &h->nom_iters, B);
     rc |= dalloc(h->owned, &h->mapA, (size_t)N * nx * nx); rc |= dalloc(h->owned, &h->mapB, (size_t)N * nx * nu);
     rc |= dalloc(h->owned, &h->inst_launches, (size_t)4); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
-    rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->Kc, B * N * nu * nx); rc |= dalloc(h->owned, &h->Aclc, B * N * nx * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
+    rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->Kc, B * N * nu * nx); rc |= dalloc(h->owned, &h->Aclc, B * N * nx * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->Gd, (size_t)ni * (nx + nu)); rc |= dalloc(h->owned, &h->Gfd, (size_t)nif * nx); h->general_G = false; rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
     h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { free_all(h->owned); hipStreamDestroy(h->st); delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
@@ -240,16 +261,22 @@ extern "C" int slsqp_set_costs(slsqp_handle *h, const double *Q, const double *R
 
 extern "C" int slsqp_set_constraints(slsqp_handle *h, const double *G, const double *Gf, const double *gf) {
     hipSetDevice(h->dev);
-    const int nx = h->d.nx, nz = h->nz;
-    for (int i = 0; i < 2 * nz; i++) for (int j = 0; j < nz; j++) {
+    const int nx = h->d.nx, nz = h->nz, ni = h->d.ni, nif = h->d.ni_f;
+    bool box = (ni == 2 * nz) && (nif == 2 * nx);
+    for (int i = 0; box && i < 2 * nz; i++) for (int j = 0; j < nz; j++) {
         const double want = (i % nz == j) ? (i < nz ? 1.0 : -1.0) : 0.0;
-        if (G[i * nz + j] != want) return fail("G must be [I;-I] (box constraints): general G is not supported by the HIP path");
+        if (G[i * nz + j] != want) { box = false; break; }
     }
-    for (int i = 0; i < 2 * nx; i++) for (int j = 0; j < nx; j++) {
+    for (int i = 0; box && i < 2 * nx; i++) for (int j = 0; j < nx; j++) {
         const double want = (i % nx == j) ? (i < nx ? 1.0 : -1.0) : 0.0;
-        if (Gf[i * nx + j] != want) return fail("Gf must be [I;-I]");
+        if (Gf[i * nx + j] != want) { box = false; break; }
     }
-    HIPCHK(hipMemcpy(h->gf_raw, gf, sizeof(double) * 2 * nx, hipMemcpyHostToDevice));
+    // general G (fast_SLS_jit.py:76-79, 138-170; Pendulum.replace_constraints): the SLS sweep takes it (k_sweep_gen); the QP solver eliminates box
+    // constraints through a diagonal Pi and does not -- slsqp_solve / slsqp_qp_* / slsqp_cl_* refuse such a handle
+    h->general_G = !box;
+    HIPCHK(hipMemcpy(h->Gd, G, sizeof(double) * (size_t)ni * nz, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->Gfd, Gf, sizeof(double) * (size_t)nif * nx, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->gf_raw, gf, sizeof(double) * nif, hipMemcpyHostToDevice));
     h->have_cons = true;
     return 0;
 }
@@ -425,9 +452,10 @@ static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int w
     if (getenv("SLSQP_NREFINE")) a.n_refine = atoi(getenv("SLSQP_NREFINE"));
     a.early_ctol = mx ? 1e-2 : 1e-6;
     auto go = [&](const QpArgs &q, bool m) {
-        if (h->d.nx == 4) return launch_qp_t<4, 1>(h, q, o->qp_max_iter, m);
-        if (h->d.nx == 13) return launch_qp_t<13, 4>(h, q, o->qp_max_iter, m);
-        return launch_qp_t<17, 4>(h, q, o->qp_max_iter, m);
+#define X(NX_, NU_) if (h->d.nx == NX_ && h->d.nu == NU_) return launch_qp_t<NX_, NU_>(h, q, o->qp_max_iter, m);
+        SLSQP_DIM_LIST
+#undef X
+        return -1;
     };
     if (go(a, mx)) return -1;
     h->mx_retry = 0;
@@ -468,15 +496,26 @@ static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, cons
     SweepArgs a;
     a.B = h->B; a.N = h->d.N; a.NW = h->d.nw; a.A = h->A; a.Bm = h->Bm; a.E = h->E; a.E_per_instance = 0; a.eta = eta; a.eta_f = eta_f;
     a.run = run; a.cst = costs_of(h); a.K = h->K; a.beta = h->beta; a.beta_f = h->beta_f; a.ct_part = h->ct_part; a.eps = eps;
+    if (h->general_G) {
+        SweepGenArgs ga{a, h->Gd, h->Gfd, h->d.ni, h->d.ni_f};
+        const dim3 grid(h->B * (h->d.N + 1)), blk(64);
+#define X(NX_, NU_) if (h->d.nx == NX_ && h->d.nu == NU_) { const size_t lds = sizeof(double) * sweep_gen_lds_doubles<NX_, NU_>(); hipLaunchKernelGGL((k_sweep_gen<NX_, NU_>), grid, blk, lds, h->st, ga); }
+        SLSQP_DIM_LIST
+#undef X
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     static const bool allow_shared = getenv("SLSQP_SWEEP_SHARED") ? atoi(getenv("SLSQP_SWEEP_SHARED")) != 0 : true;
     if (shared_cols && allow_shared) {
-        if (h->d.nx == 4) return launch_sweep_shared_t<4, 1>(h, a);
-        if (h->d.nx == 13) return launch_sweep_shared_t<13, 4>(h, a);
-        return launch_sweep_shared_t<17, 4>(h, a);
+#define X(NX_, NU_) if (h->d.nx == NX_ && h->d.nu == NU_) return launch_sweep_shared_t<NX_, NU_>(h, a);
+        SLSQP_DIM_LIST
+#undef X
+        return -1;
     }
-    if (h->d.nx == 4) return launch_sweep_t<4, 1>(h, a);
-    if (h->d.nx == 13) return launch_sweep_t<13, 4>(h, a);
-    return launch_sweep_t<17, 4>(h, a);
+#define X(NX_, NU_) if (h->d.nx == NX_ && h->d.nu == NU_) return launch_sweep_t<NX_, NU_>(h, a);
+    SLSQP_DIM_LIST
+#undef X
+    return -1;
 }
 
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
@@ -484,6 +523,7 @@ static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTi
 // `active` (device, B ints or NULL = all): instances that take part in this call; the others keep every result array untouched.
 static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts, const int *active) {
     hipSetDevice(h->dev);
+    if (h->general_G) return fail("general G: only the sweep-level boundary (slsqp_sweep) is available; the QP solver needs box constraints G = [I;-I]");
     if (!h->have_costs || !h->have_cons || !h->have_dyn) return fail("set_costs, set_constraints and update_dynamics must be called first");
     slsqp_opts o;
     if (opts) o = *opts; else slsqp_default_opts(&o);
@@ -528,7 +568,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         HIPCHK(hipEventRecord(h->ev[3], h->st));
         if (launch_sweep(h, h->mask, h->eta, h->eta_f, o.eps_backoff, /* beta == eps for every column right after initialize_backoff */ i == 0)) return -1;
         HIPCHK(hipEventRecord(h->ev[4], h->st));
-        TightenArgs ta{B, d.N, d.nx, d.nu, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1, h->ct_part, h->cost_tube};
+        TightenArgs ta{B, d.N, d.nx, d.nu, d.ni, d.ni_f, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1, h->ct_part, h->cost_tube};
         hipLaunchKernelGGL(k_tighten, dim3(B), dim3(128), 0, h->st, ta);
         int nmask = 0;
         HIPCHK(hipMemcpyAsync(&nmask, h->counter, sizeof(int), hipMemcpyDeviceToHost, h->st));
@@ -621,6 +661,7 @@ extern "C" int slsqp_reset(slsqp_handle *h) {
 // ---- linearisation step in front of the path (SCP_SLS.update_jacobian) ----------------------------------------------
 extern "C" int slsqp_set_model(slsqp_handle *h, int model_id, const double *g_raw) {
     hipSetDevice(h->dev);
+    if (h->general_G) return fail("general G: the plants of slsqp_set_model have box constraints");
     const int want_nx = model_id == 0 ? 4 : (model_id == 1 ? 13 : (model_id == 2 ? 17 : -1));
     if (want_nx != h->d.nx) return fail("model id does not match the handle's dimensions (0 pendulum, 1 quadrotor, 2 rocket)");
     HIPCHK(hipMemcpy(h->g_raw, g_raw, sizeof(double) * h->d.ni, hipMemcpyHostToDevice));
@@ -712,6 +753,7 @@ extern "C" int slsqp_cl_init(slsqp_handle *h, const double *x_meas, const double
 // handle (slsqp_cl_init: caller's guess or roll-out) and the measured state given there.
 extern "C" int slsqp_nominal_solve(slsqp_handle *h, int max_qp, double tol, double rho, const slsqp_opts *opts) {
     hipSetDevice(h->dev);
+    if (h->general_G) return fail("general G: only the sweep-level boundary (slsqp_sweep) is available; the QP solver needs box constraints G = [I;-I]");
     if (h->model_id < 0 || !h->have_costs || !h->have_cons) return fail("set_model, set_costs and set_constraints must be called first");
     slsqp_opts o;
     if (opts) o = *opts; else slsqp_default_opts(&o);
@@ -906,6 +948,7 @@ extern "C" int slsqp_qp_update_data_vec(slsqp_handle *h, const double *q, const 
 
 extern "C" int slsqp_qp_solve(slsqp_handle *h, double *x, double *y, int *status, int *iters, int loc, const slsqp_opts *opts) {
     hipSetDevice(h->dev);
+    if (h->general_G) return fail("general G: only the sweep-level boundary (slsqp_sweep) is available; the QP solver needs box constraints G = [I;-I]");
     if (!h->have_costs) return fail("costs not set");
     slsqp_opts o;
     if (opts) o = *opts; else slsqp_default_opts(&o);
@@ -942,7 +985,7 @@ extern "C" int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta
     HIPCHK(hipEventRecord(h->ev[0], h->st));
     if (launch_sweep(h, nullptr, h->eta, h->eta_f, 1e-10)) return -1;
     HIPCHK(hipEventRecord(h->ev[1], h->st));
-    TightenArgs ta{h->B, d.N, d.nx, d.nu, h->beta, h->beta_f, h->g, h->gf_raw, h->c, nullptr, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 0, h->ct_part, h->cost_tube};
+    TightenArgs ta{h->B, d.N, d.nx, d.nu, d.ni, d.ni_f, h->beta, h->beta_f, h->g, h->gf_raw, h->c, nullptr, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 0, h->ct_part, h->cost_tube};
     hipLaunchKernelGGL(k_tighten, dim3(h->B), dim3(128), 0, h->st, ta);
     HIPCHK(hipEventRecord(h->ev[2], h->st));
     HIPCHK(hipStreamSynchronize(h->st));

@@ -1470,6 +1470,161 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep(SweepArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// SLS sweep for a general constraint matrix G (ni x (nx+nu)), Gf (ni_f x nx) -- what the reference's kernels take
+// (fast_SLS_jit.py:76-79: C = G' diag(eta) G, its x-x and u-u blocks, cross block ignored; :138-170: beta_i = || G_x,i Phi_x + G_u,i Phi_u ||^2;
+// Pendulum.replace_constraints, dyn/pendulum.py:146, builds such a model).  Same mapping as k_sweep (one wave per (instance, column)); the
+// constraint-dependent parts run on the vector ALU from G in global memory -- this is the sweep-level boundary's path (slsqp_sweep), not the
+// closed loop's, where every plant of the reference has G = [I;-I].
+// ------------------------------------------------------------------------------------------------
+struct SweepGenArgs { SweepArgs s; const double *G, *Gf; int NI, NIF; };
+template <int NX, int NU>
+__host__ __device__ constexpr int sweep_gen_lds_doubles() { return 4 * NX * NX + 5 * NX * NU + 2 * NU * NU + 8; }
+template <int NX, int NU>
+__global__ __launch_bounds__(64) void k_sweep_gen(SweepGenArgs ga) {
+    const SweepArgs &a = ga.s;
+    constexpr int NZ = NX + NU, NW = NX;
+    const int N = a.N, lane = threadIdx.x, NI = ga.NI, NIF = ga.NIF;
+    const int ncol = N + 1, b = blockIdx.x / ncol, j = blockIdx.x % ncol;
+    if (b >= a.B || (a.run && !a.run[b])) return;
+    extern __shared__ double sm[];
+    double *p = sm;
+    double *sA = p; p += NX * NX; double *sS = p; p += NX * NX; double *sYm = p; p += NX * NX; double *sCx = p; p += NX * NX;
+    double *sAcl = sA, *sSn = sS, *sPhi = sS, *sPhi2 = sYm;
+    double *sB = p; p += NX * NU; double *sX = p; p += NX * NU; double *sF = p; p += NX * NU; double *sK = p; p += NX * NU;
+    double *sPu = p; p += NU * NW; double *sH = p; p += NU * NU; double *sCu = p; p += NU * NU;
+    const double *gA = a.A + (size_t)b * N * NX * NX, *gB = a.Bm + (size_t)b * N * NX * NU;
+    const double *eta = a.eta + (size_t)b * N * N * NI, *eta_f = a.eta_f + (size_t)b * (N + 1) * NIF;
+    double *gK = a.K + (size_t)b * N * (N + 1) * NU * NX;
+    double *beta = a.beta + (size_t)b * N * N * NI, *beta_f = a.beta_f + (size_t)b * (N + 1) * NIF;
+    const double *G = ga.G, *Gf = ga.Gf;
+    // terminal: S[N,j] = Gf' diag(eta_f[j]) Gf + Q_reg_f
+    for (int o = lane; o < NX * NX; o += 64) {
+        const int i = o / NX, jj = o % NX;
+        double s = (i == jj) ? a.cst.Qregfd[i] : 0.0;
+        for (int r = 0; r < NIF; r++) s = fma(Gf[r * NX + i] * eta_f[j * NIF + r], Gf[r * NX + jj], s);
+        sS[o] = s;
+    }
+    wla::wsync();
+    for (int k = N - 1; k >= j; k--) {
+        const double *Ak = gA + (size_t)k * NX * NX, *Bk = gB + (size_t)k * NX * NU, *e = eta + ((size_t)k * N + j) * NI;
+        for (int o = lane; o < NX * NX; o += 64) {
+            const int i = o / NX, jj = o % NX;
+            sA[o] = Ak[o];
+            double s = (i == jj) ? a.cst.Qregd[i] : 0.0;                                   // C_xx + Q_reg
+            for (int r = 0; r < NI; r++) s = fma(G[r * NZ + i] * e[r], G[r * NZ + jj], s);
+            sCx[o] = s;
+        }
+        for (int o = lane; o < NX * NU; o += 64) sB[o] = Bk[o];
+        for (int o = lane; o < NU * NU; o += 64) {
+            const int i = o / NU, jj = o % NU;
+            double s = (i == jj) ? a.cst.Rregd[i] : 0.0;                                   // C_uu + R_reg
+            for (int r = 0; r < NI; r++) s = fma(G[r * NZ + NX + i] * e[r], G[r * NZ + NX + jj], s);
+            sCu[o] = s;
+        }
+        wla::wsync();
+        wla::gemm_blk<NU, NX, NX, true, false, 1, 2, false>(sB, NU, sS, NX, sX, NX, 1.0, lane);   // x = B' S
+        wla::gemm_blk<NX, NX, NX, true, false, 3, 2, false>(sA, NX, sS, NX, sYm, NX, 1.0, lane);  // y = A' S
+        wla::wsync();
+        for (int o = lane; o < NU * NU; o += 64) {                                                // H = C_uu + R_reg + x B
+            const int i = o / NU, jj = o % NU;
+            double s = sCu[o];
+            for (int kk = 0; kk < NX; kk++) s = fma(sX[i * NX + kk], sB[kk * NU + jj], s);
+            sH[o] = s;
+        }
+        wla::gemm_blk<NU, NX, NX, false, false, 1, 2, false>(sX, NX, sA, NX, sF, NX, 1.0, lane);  // F = x A
+        wla::wsync();
+        if (lane < NX) {   // K = -H^{-1} F, one column per lane (H symmetric positive definite: C_uu is a Gram matrix, R_reg > 0, x B = B' S B)
+            double f[NU];
+#pragma unroll
+            for (int u = 0; u < NU; u++) f[u] = sF[u * NX + lane];
+            wla::spd_solve_small<NU>(sH, NU, f);
+#pragma unroll
+            for (int u = 0; u < NU; u++) sK[u * NX + lane] = -f[u];
+        }
+        wla::wsync();
+        double *Kg = gK + ((size_t)k * (N + 1) + j) * NU * NX;
+        for (int o = lane; o < NU * NX; o += 64) Kg[o] = sK[o];
+        for (int o = lane; o < NX * NX; o += 64) {                                                // Acl = A + B K
+            const int i = o / NX, jj = o % NX;
+            double s = sA[o];
+#pragma unroll
+            for (int u = 0; u < NU; u++) s = fma(sB[i * NU + u], sK[u * NX + jj], s);
+            sAcl[o] = s;
+        }
+        wla::wsync();
+        wla::gemm_blk<NX, NX, NX, false, false, 3, 2, false>(sYm, NX, sAcl, NX, sSn, NX, 1.0, lane);  // y (A + B K)
+        wla::wsync();
+        for (int o = lane; o < NX * NX; o += 64) {   // S = C_xx + Q_reg + sym(y Acl), in place
+            const int i = o / NX, jj = o % NX;
+            if (i >= jj) {
+                const double v = 0.5 * (sSn[o] + sSn[jj * NX + i]) + 0.5 * (sCx[o] + sCx[jj * NX + i]);
+                sS[o] = v; sS[jj * NX + i] = v;
+            }
+        }
+        wla::wsync();
+    }
+    wla::wsync_mem();
+    // propagate column j, beta from the rows of G [Phi_x; Phi_u]
+    const double *Eg = a.E + (a.E_per_instance ? (size_t)b * (N + 1) * NX * NW : 0) + (size_t)j * NX * NW;
+    for (int o = lane; o < NX * NW; o += 64) sPhi[o] = Eg[o];
+    wla::wsync();
+    double *Pc = sPhi, *Pn = sPhi2;
+    double ctube = 0.0;
+    for (int k = j; k < N; k++) {
+        const double *Ak = gA + (size_t)k * NX * NX, *Bk = gB + (size_t)k * NX * NU, *Kg = gK + ((size_t)k * (N + 1) + j) * NU * NX;
+        for (int o = lane; o < NX * NX; o += 64) sA[o] = Ak[o];
+        for (int o = lane; o < NX * NU; o += 64) { sB[o] = Bk[o]; sK[o] = Kg[o]; }
+        wla::wsync();
+        wla::gemm_blk<NU, NW, NX, false, false, 1, 2, false>(sK, NX, Pc, NW, sPu, NW, 1.0, lane);  // Phi_u = K Phi_x
+        for (int o = lane; o < NX * NX; o += 64) {
+            const int i = o / NX, jj = o % NX;
+            double s = sA[o];
+#pragma unroll
+            for (int u = 0; u < NU; u++) s = fma(sB[i * NU + u], sK[u * NX + jj], s);
+            sAcl[o] = s;
+        }
+        wla::wsync();
+        for (int r = lane; r < NI; r += 64) {
+            double s = 0.0;
+            for (int w = 0; w < NW; w++) {
+                double v = 0.0;
+                for (int c = 0; c < NX; c++) v = fma(G[r * NZ + c], Pc[c * NW + w], v);
+                for (int c = 0; c < NU; c++) v = fma(G[r * NZ + NX + c], sPu[c * NW + w], v);
+                s = fma(v, v, s);
+            }
+            beta[((size_t)k * N + j) * NI + r] = fmax(s, a.eps);
+        }
+        if (lane < NZ) {   // this column's share of cost_tube^2 (weighted row norms of [Phi_x; Phi_u])
+            const double *row = (lane < NX) ? Pc + lane * NW : sPu + (lane - NX) * NW;
+            double s = 0.0;
+            for (int w = 0; w < NW; w++) s = fma(row[w], row[w], s);
+            const double wr = (lane < NX) ? a.cst.Qregd[lane] : a.cst.Rregd[lane - NX];
+            ctube = fma(wr * wr, s, ctube);
+        }
+        wla::gemm_blk<NX, NW, NX, false, false, 3, 2, false>(sAcl, NX, Pc, NW, Pn, NW, 1.0, lane);    // Phi_{k+1} = Acl Phi_k
+        wla::wsync();
+        double *t = Pc; Pc = Pn; Pn = t;
+    }
+    for (int r = lane; r < NIF; r += 64) {
+        double s = 0.0;
+        for (int w = 0; w < NW; w++) {
+            double v = 0.0;
+            for (int c = 0; c < NX; c++) v = fma(Gf[r * NX + c], Pc[c * NW + w], v);
+            s = fma(v, v, s);
+        }
+        beta_f[j * NIF + r] = fmax(s, a.eps);
+    }
+    if (lane < NX) {
+        const double *row = Pc + lane * NW;
+        double s = 0.0;
+        for (int w = 0; w < NW; w++) s = fma(row[w], row[w], s);
+        ctube = fma(a.cst.Qregfd[lane] * a.cst.Qregfd[lane], s, ctube);
+    }
+    ctube = wla::wave_sum(ctube);
+    if (lane == 0 && a.ct_part) a.ct_part[(size_t)b * (N + 1) + j] = ctube;
+}
+
+// ------------------------------------------------------------------------------------------------
 // The sweep of the FIRST fast-SLS iteration of a solve.  initialize_backoff (fast_SLS_jit.py:444-454) has just reset every beta[k,j] to eps, so
 // evaluate_dual_eta (:475-487) gives eta[k,j] = mu_k / (2 sqrt(eps)) for every column j <= k and eta_f[j] = mu_f / (2 sqrt(eps)) for every j: the
 // cost blocks of the N+1 Riccati recursions of _backward_solve_numba (:65-84) are the same, hence S[k,j] = S[k], K[k,j] = K[k] and
@@ -1706,7 +1861,7 @@ __global__ __launch_bounds__(64, 4) void k_sweep_prop(SweepSharedArgs aa) {
 // backoff sums + tightened bounds (fast_SLS_jit.py:173-186, 556-569) ; one workgroup per instance
 // ------------------------------------------------------------------------------------------------
 struct TightenArgs {
-    int B, N, NX, NU;
+    int B, N, NX, NU, NI, NIF;   // NI, NIF: rows of G, Gf (2(nx+nu), 2nx for the box constraints of the reference's plants)
     const double *beta, *beta_f, *g, *gf_raw, *c;
     const int *run;
     double *backoff, *backoff_f, *backoff_x, *backoff_u, *ubg;
@@ -1716,7 +1871,7 @@ struct TightenArgs {
 __global__ void k_tighten(TightenArgs a) {
     const int b = blockIdx.x;
     if (a.run && !a.run[b]) return;
-    const int NX = a.NX, NU = a.NU, NZ = NX + NU, NI = 2 * NZ, NIF = 2 * NX, N = a.N, SR = NX + NI, mb = N * SR + NIF;
+    const int NX = a.NX, NU = a.NU, NZ = NX + NU, NI = a.NI, NIF = a.NIF, N = a.N, SR = NX + NI, mb = N * SR + NIF;
     const double *be = a.beta + (size_t)b * N * N * NI, *bf = a.beta_f + (size_t)b * (N + 1) * NIF;
     double *bo = a.backoff + (size_t)b * N * NI, *bof = a.backoff_f + (size_t)b * NIF;
     double *bx = a.backoff_x + (size_t)b * (N + 1) * NX, *bu = a.backoff_u + (size_t)b * N * NU;

@@ -23,7 +23,7 @@ def relerr(a, b):
 
 
 SWEEP_CASES = ["sweep_pendulum_N10_s0.npz", "sweep_pendulum_N3_s2.npz", "sweep_quadrotor_N20_s0.npz", "sweep_rocket_N20_s0.npz",
-               "sweep_rocket_N5_s1.npz"]
+               "sweep_rocket_N5_s1.npz", "sweep_pendulum_N10_s1_genG.npz"]
 
 
 @pytest.mark.parametrize("case", SWEEP_CASES)
@@ -34,6 +34,13 @@ def test_sweep_vs_reference_golden(case):
     m = get_model(name)
     N = int(g["N"])
     B = 3
+    if "genG" in case:
+        # a model with a general constraint matrix (7 x 5 and 5 x 4 random rows; the reference's kernels take any G, fast_SLS_jit.py:76-79,
+        # 138-170): the sweep-level boundary accepts it (k_sweep_gen), the QP-level entry points refuse it loudly
+        from types import SimpleNamespace
+        base = m
+        m = SimpleNamespace(nx=base.nx, nu=base.nu, nw=base.nw, ni=int(g["ni"]), ni_f=int(g["ni_f"]), G=g["G"], Gf=g["Gf"], gf=np.zeros(int(g["ni_f"])),
+                            E=base.E, Q=base.Q, R=base.R, Qf=base.Qf)
     f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, g["Q_reg"], g["R_reg"], g["Q_reg_f"], batch=B)
     rng = np.random.default_rng(5)
     # instance 0 = the golden case; the others are perturbed copies (must not disturb instance 0)
@@ -42,6 +49,9 @@ def test_sweep_vs_reference_golden(case):
     zeros = lambda *s: np.zeros(s)
     f.update_dynamics_list(A, Bm, g["E"], zeros(B, N, m.ni), zeros(B, m.ni_f), zeros(B, N, m.nx))
     out = f.sweep(np.stack([g["eta"]] * B), np.stack([g["eta_f"]] * B))
+    if "genG" in case:
+        with pytest.raises(RuntimeError, match="general G"):
+            f.solve(np.zeros((B, m.nx)))
     f.close()
     assert relerr(out["K"][0], g["K"]) < 1e-9
     assert relerr(out["beta"][0], g["beta"]) < 1e-9
@@ -63,6 +73,25 @@ def test_sweep_vs_reference_golden(case):
             want = np.sqrt(((q * g["Phix_fro"][:N]) ** 2).sum() + ((qf * g["Phix_fro"][N]) ** 2).sum() + ((r * g["Phiu_fro"]) ** 2).sum())
     if want is not None:
         assert abs(out["cost_tube_value"][0] - want) < 1e-9 * max(1.0, want)
+
+
+def test_extra_dims_build():
+    """The (nx, nu) pairs the kernels exist for are a build-time list (csrc/slsqp_api.hip SLSQP_DIM_LIST; -DSLSQP_EXTRA_DIMS adds pairs):
+    __graft_entry__.build() also builds libslsqp_hip_dims62.so with (6,2) added, and a fast-SLS step of a random (6,2) plant solved through
+    it matches the oracle (child process: the library is chosen at import time)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    so = os.path.join(ROOT, "robust-nonlinear-mpc_amd", "csrc", "libslsqp_hip_dims62.so")
+    assert os.path.exists(so), "run __graft_entry__.build()"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dims_extra_check.py")], env=dict(os.environ, SLSQP_SO=so), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "extra dims ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    from robust_nonlinear_mpc_amd import BatchedFastSLS
+    from types import SimpleNamespace
+    nx, nu = 6, 2
+    m = SimpleNamespace(nx=nx, nu=nu, nw=nx, ni=16, ni_f=12, G=np.vstack([np.eye(8), -np.eye(8)]), Gf=np.vstack([np.eye(6), -np.eye(6)]), gf=np.ones(12), E=np.eye(6))
+    with pytest.raises(RuntimeError, match="unsupported"):      # the default library does not carry (6,2) and says which pairs it has
+        BatchedFastSLS(8, np.eye(nx), np.eye(nu), m, np.eye(nx), batch=2)
 
 
 @pytest.mark.parametrize("model,amps", [("pendulum", (0.2, 1.0)), ("quadrotor", (0.2, 1.0, 2.0)), ("rocket", (0.2, 1.0))])

@@ -4,6 +4,7 @@
 // per-instance masks, so one infeasible or converged instance never stalls or fails the batch.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -379,7 +380,8 @@ __global__ void k_join_y(int B, int mb, int nx, const double *dual, const double
 // ---- kernel dispatch ---------------------------------------------------------------------------------------
 template <int NX, int NU>
 static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter, bool mx) {
-    const size_t lds = mx ? QpLdsMx<NX, NU>::BYTES : sizeof(double) * qp_lds_doubles<NX, NU>(h->d.N);
+    // the fp64 kernels' LDS also holds two n-vectors of the phase logic between the sweeps (phase_update, fused look)
+    const size_t lds = mx ? QpLdsMx<NX, NU>::BYTES : sizeof(double) * (size_t)std::max(qp_lds_doubles<NX, NU>(h->d.N), 2 * h->n + 8);
     const dim3 grid(h->B), blk(64);
     // every instance needs 1 (start) + 2 per interior-point iteration + (1 + n_refine) per polish round ticks, after at most warm_rounds + as_rounds
     // active-set rounds of the attempts that precede the interior point

@@ -560,7 +560,7 @@ __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
 
 // first = 1: set up the instance (x0-pin check, starting rhs); else consume the solve of the current phase.
 template <int NX, int NU>
-__device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, int lane) {
+__device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, int lane, double *sm = nullptr) {
     using L = Lay<NX, NU>;
     constexpr int NZ = L::NZ, SR = L::SR;
     const int N = a.N, n = L::n(N), mb = L::mb(N);
@@ -768,7 +768,11 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
     } else {
         // polish phases: zn = v - Pi g  (v was z0 - Pi r or zn - Pi r1); CU := zn, CL := accumulated E' nu
         const bool firstp = (phase == P_POL0);
-        if (!as_from_init) {
+        const double max_rounds = (s.warm == 1.0) ? (double)a.warm_rounds : (s.warm == 2.0 ? (double)a.as_rounds : 8.0);
+        // the look at an un-refined solve (the common tick of an active-set attempt) runs fused below when the wave's LDS is at hand
+        const bool look = (phase == P_POL0 && s.pol_fail == 0.0 && s.pol_round < max_rounds);
+        const bool fused_look = look && sm != nullptr;
+        if (!as_from_init && !fused_look) {
 #pragma unroll 4
             for (int e = lane; e < n; e += 64) {
                 const double gg = G[e];
@@ -778,7 +782,6 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             for (int o = lane; o < N * NX; o += 64) NUP[o] = (firstp ? 0.0 : NUP[o]) + W[o];
             wla::wsync_mem();
         }
-        const double max_rounds = (s.warm == 1.0) ? (double)a.warm_rounds : (s.warm == 2.0 ? (double)a.as_rounds : 8.0);
         // Correction of the active set from the solve in CU (primal) / CL (E'nu): multipliers of the wrong sign leave, violated bounds enter --
         // all of them for the inputs (control constraints are active on arcs), but for a state component only the stages where its violation
         // has a local maximum along the horizon: state constraints are active at isolated touch points, and fixing a whole violated arc at once
@@ -857,19 +860,97 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             }
         };
         bool again = false, give_up = false;
-        if (phase == P_POL0 && s.pol_fail == 0.0 && s.pol_round < max_rounds) {
+        // The same look in one trip to memory: every global array is read once (pass A), the primal zn and E'nu go back out, each element's
+        // violation and its set entry after the releases go to LDS (free between the sweeps), the neighbour tests of the local-maximum rule
+        // read them there (pass B), and the new set is applied from LDS (pass C).  The unfused version below makes five dependent trips
+        // (update zn, input pre-pass, plan, apply, ...): 45 us per tick with 3 waves per SIMD contending for memory, against 15 us alone.
+        auto fused_plan = [&](double tolv, double &nv, unsigned long long &hash) -> double {
+            double *sV = sm, *sN = sm + n;
+            int in_viol = 0;
+            double viols = 0.0;
+#pragma unroll 2
+            for (int e = lane; e < n; e += 64) {
+                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                double zn, cl;
+                if (as_from_init) { zn = CU[e]; cl = CL[e]; }
+                else {
+                    const double gg = G[e];
+                    zn = V[e] - PI[e] * gg; cl = (firstp ? 0.0 : CL[e]) + gg;
+                    CU[e] = zn; CL[e] = cl;
+                }
+                const double gr = el.pd * zn + el.q + cl, ac = ACT[e];
+                double nac = ac;
+                if (ac > 0.0 && gr > tolv) nac = 0.5;          // 0.5: released in this round (reads as "not in the set" below, counts as a change)
+                if (ac < 0.0 && -gr > tolv) nac = 0.5;
+                double v = 0.0;
+                if (ac == 0.0 && el.fr) {
+                    const double vu = el.fu ? zn - el.hi : 0.0, vl = el.fl ? el.lo - zn : 0.0, vm = fmax(vu, vl);
+                    if (vm > tolv) { v = vu > vl ? vm : -vm; viols += 1.0; if ((e % NZ) >= NX) in_viol = 1; }
+                }
+                sV[e] = v; sN[e] = nac;
+            }
+            if (!as_from_init) for (int o = lane; o < N * NX; o += 64) NUP[o] = (firstp ? 0.0 : NUP[o]) + W[o];
+            wla::wsync();
+            const bool any_in = wla::wave_or(in_viol) != 0;
+            double changed = 0.0, kfirst = 1e9;
+            unsigned long long hv = 0ULL;
+#pragma unroll 2
+            for (int e = lane; e < n; e += 64) {
+                const double v = sV[e];
+                double nac = sN[e];
+                bool chg = (nac == 0.5);
+                if (chg) nac = 0.0;
+                if (v != 0.0) {
+                    bool take = true;
+                    if ((e % NZ) < NX) {
+                        const double va = fabs(v), vp = (e - NZ >= NX) ? fabs(sV[e - NZ]) : 0.0, vn = (e + NZ < n) ? fabs(sV[e + NZ]) : 0.0;
+                        take = !any_in && va >= vp && va >= vn;
+                    }
+                    if (take) { nac = v > 0.0 ? 1.0 : -1.0; chg = true; }
+                }
+                if (chg) { changed += 1.0; kfirst = fmin(kfirst, (double)max(0, e / NZ - ((e % NZ) < NX ? 1 : 0))); }
+                if (nac != 0.0) {
+                    unsigned long long x = (unsigned long long)(2 * e + (nac > 0.0 ? 1 : 0)) + 0x9E3779B97F4A7C15ULL;
+                    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; hv ^= x ^ (x >> 31);
+                }
+                // (own element only: no other lane reads sN)
+                sN[e] = nac;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned lo32 = __shfl_xor((unsigned)(hv & 0xFFFFFFFFULL), o), hi32 = __shfl_xor((unsigned)(hv >> 32), o);
+                hv ^= ((unsigned long long)hi32 << 32) | lo32;
+            }
+            hash = hv | 1ULL;
+            nv = wla::wave_sum(viols);
+            s.kmin = fmin(wla::wave_min(kfirst), (double)N);
+            return wla::wave_sum(changed);
+        };
+        auto fused_apply = [&]() {
+            const double *sN = sm + n;
+#pragma unroll 4
+            for (int e = lane; e < n; e += 64) {
+                const Elem el = elem_of<NX, NU>(e, n, N, ub, qg, cst);
+                const double ac = sN[e];
+                const double z0 = ac > 0.0 ? el.hi : (ac < 0.0 ? el.lo : 0.0);
+                const double pi = (el.fr && ac == 0.0) ? wla::fast_rcp(el.pd) : 0.0;
+                ACT[e] = ac; PI[e] = pi; V[e] = (pi != 0.0) ? -pi * el.q : ((e < NX) ? a.x0val[(size_t)b * NX + e] : z0);
+            }
+        };
+        if (look) {
             // cheap look at the un-refined solve: if the active set is visibly wrong (coarse tolerance) correct it now and
             // factorise again, without spending the refinement solve on a set that is about to change
             double nv = 0.0;
             unsigned long long hsh = 0ULL;
-            const double changed = plan_set(a.early_ctol * qscale, nv, hsh);
+            const double changed = fused_look ? fused_plan(a.early_ctol * qscale, nv, hsh) : plan_set(a.early_ctol * qscale, nv, hsh);
             again = changed > 0.0;
             if (again && s.warm > 0.0 && seen_before(hsh)) { again = false; give_up = true; }
             // an attempt (warm or from the empty set) whose solve blows up -- a set that pins both ends of a dynamics row leaves hundreds of
             // violated bounds -- is left to the interior point at once
             if (s.warm > 0.0 && (nv > (double)a.as_max_viol || (s.pol_round > 0.0 && nv > 2.0 * s.nviol + 8.0))) { again = false; give_up = true; }
             s.nviol = nv;
-            if (again) { s.pol_round += 1.0; apply_set(); s.uf_valid = 1.0; }      // the sweep just consumed solved the un-refined system of this attempt
+            if (again) { s.pol_round += 1.0; if (fused_look) fused_apply(); else apply_set(); s.uf_valid = 1.0; }      // the sweep just consumed solved the un-refined system of this attempt
+            if (fused_look) wla::wsync_mem();
         } else if (phase == P_POL0 && s.warm > 0.0) give_up = true;      // out of rounds (or a pivot failed): do not refine a set known to be wrong
         if (again) {
             phase = P_POL0;
@@ -1072,13 +1153,13 @@ __global__ __launch_bounds__(64) void k_ne_bwd_phase(QpArgs a) {
     wla::wsync_mem();
     const long long t1_ = __builtin_readcyclecounter();
     const bool rec = (int)st->phase == P_INIT;
-    phase_update<NX, NU>(a, 0, b, lane);
+    phase_update<NX, NU>(a, 0, b, lane, sm);
     wla::wsync_mem();
     if (rec && lane == 0) { dbg[4] = t1_ - t0_; dbg[5] = __builtin_readcyclecounter() - t1_; }
 #else
     ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
     wla::wsync_mem();
-    phase_update<NX, NU>(a, 0, b, lane);
+    phase_update<NX, NU>(a, 0, b, lane, sm);
 #endif
 }
 
@@ -1097,6 +1178,13 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
     phase_update<NX, NU>(a, 1, b, lane);
     wla::wsync_mem();
     unsigned long long n_sweeps = 0, n_factor = 0, n_fstages = 0;
+#ifdef QP_STAMP
+    long long c_fwd = 0, c_bwd = 0, c_ph = 0, c_t0 = __builtin_readcyclecounter(), c_fwdf = 0;
+#define QSTAMP(acc) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc += t_ - c_last; c_last = t_; } while (0)
+    long long c_last = c_t0;
+#else
+#define QSTAMP(acc) do {} while (0)
+#endif
     for (int t = 0; t < max_ticks; t++) {
         // The instance index and the lane id are laundered through empty asm statements at the head of every part: nothing computed from them
         // is loop-invariant for the compiler then, so it cannot hoist the phase logic's per-element loads (bounds, weights, linear cost) out of
@@ -1117,15 +1205,23 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
         }
         n_sweeps++; n_factor += factor ? 1 : 0; n_fstages += factor ? (unsigned long long)(a.N - fp.k0) : 0ULL;
         wla::wsync_mem();
+#ifdef QP_STAMP
+        if (factor) QSTAMP(c_fwdf); else QSTAMP(c_fwd);
+#endif
         asm volatile("" : "+s"(b));
         asm volatile("" : "+v"(lane));
         ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
         wla::wsync_mem();
+        QSTAMP(c_bwd);
         asm volatile("" : "+s"(b));
         asm volatile("" : "+v"(lane));
-        phase_update<NX, NU>(a, 0, b, lane);
+        phase_update<NX, NU>(a, 0, b, lane, sm);
         wla::wsync_mem();
+        QSTAMP(c_ph);
     }
+#ifdef QP_STAMP
+    if (lane == 0) { double *kk = a.kkt + (size_t)b * 8; kk[2] = (double)c_fwdf; kk[3] = (double)(double)n_fstages; kk[4] = (double)c_fwd; kk[5] = (double)c_bwd; kk[6] = (double)c_ph; kk[7] = (double)(__builtin_readcyclecounter() - c_t0); }
+#endif
     if (lane == 0) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); atomicAdd(a.inst_launches + 2, n_fstages); atomicAdd(a.inst_launches + 3, 1ULL); }
 }
 

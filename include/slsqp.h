@@ -61,7 +61,7 @@ typedef struct {
                             if the polish then fails to certify, the interior point resumes down to 1e-9 and the polish is repeated */
     double conv_tol;     /* primal convergence test of check_convergence_socp (1e-3, fast_SLS_jit.py:594) */
     double eps_backoff;  /* epsilon_backoff (1e-10, fast_SLS_jit.py:205) */
-    int want_K;          /* also keep K (N,N+1,nu,nx) for slsqp_get */
+    int want_K;          /* accepted and ignored: K (N,N+1,nu,nx) is always kept (the propagation of the sweep reads it back) */
     int warm_start;      /* 1 (default): the first QP of a call first tries an active-set polish from the instance's previous
                             certified solution (KKT-verified, falls back to the interior point); later QPs of a call always do */
     int warm_rounds;     /* active-set correction rounds a warm attempt may use before falling back (default 10) */

@@ -19,6 +19,18 @@ cd $root
 for sl in 3 1; do
   f=$(ls $out/stats_s$sl/*kernel_stats.csv $out/stats_s$sl/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp $f $out/kernel_stats_s$sl.csv
+  # per-dispatch durations of the dominant kernel (the bench's roofline averages the launches of its timed region = the last 2 x steps x slices of them)
+  t=$(ls $out/stats_s$sl/*kernel_trace.csv $out/stats_s$sl/*/*kernel_trace.csv 2>/dev/null | head -1)
+  [ -n "$t" ] && python3 - "$t" $out/k_qp_solve_dispatches_s$sl.csv <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_qp_solve" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+with open(sys.argv[2], "w") as f:
+    f.write("index,start_ns,duration_ns,grid_x\n")
+    t0 = int(rows[0]["Start_Timestamp"]) if rows else 0
+    for i, r in enumerate(rows):
+        f.write(f"{i},{int(r['Start_Timestamp']) - t0},{int(r['End_Timestamp']) - int(r['Start_Timestamp'])},{r.get('Grid_Size_X', r.get('Grid_Size', ''))}\n")
+PY
   python3 scripts/pmc_traffic.py $out/pmc_s$sl $out/pmc_traffic_s$sl.json "$(git rev-parse --short HEAD 2>/dev/null || echo worktree)" "$cmd --slices $sl" > /dev/null
 done
 python3 scripts/pmc_sq.py $out/pmc_sq $out/pmc_sq.json > $out/pmc_sq_summary.txt 2>&1

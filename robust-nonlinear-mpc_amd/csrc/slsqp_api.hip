@@ -62,6 +62,7 @@ struct slsqp_handle {
     double *stage;     // staging buffer for host<->device transfers
     size_t stage_bytes;
     bool have_costs, have_cons, have_dyn;
+    bool beta_inited;           // beta / beta_f have been filled with eps once (k_init_backoff); later solves only repair swept instances (k_fix_beta)
     bool general_G;             // G, Gf are not [I;-I]: only the sweep-level boundary (slsqp_sweep) is available
     double *Gd, *Gfd;           // device copies of G (ni, nx+nu) and Gf (ni_f, nx) when general_G
     hipEvent_t ev[8];
@@ -156,7 +157,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(h->owned, &h->nom_st, B * 12); rc |= dalloc(h->owned, &h->nom_need_lin, B); rc |= dalloc(h->owned, &h->nom_status, B); rc |= dalloc(h->owned, &h->nom_iters, B);
     rc |= dalloc(h->owned, &h->mapA, (size_t)N * nx * nx); rc |= dalloc(h->owned, &h->mapB, (size_t)N * nx * nu);
     rc |= dalloc(h->owned, &h->inst_launches, (size_t)4); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
-    rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->Kc, B * N * nu * nx); rc |= dalloc(h->owned, &h->Aclc, B * N * nx * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->Gd, (size_t)ni * (nx + nu)); rc |= dalloc(h->owned, &h->Gfd, (size_t)nif * nx); h->general_G = false; rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
+    rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->Kc, B * N * nu * nx); rc |= dalloc(h->owned, &h->Aclc, B * N * nx * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->Gd, (size_t)ni * (nx + nu)); rc |= dalloc(h->owned, &h->Gfd, (size_t)nif * nx); h->general_G = false; h->beta_inited = false; rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
     h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { free_all(h->owned); hipStreamDestroy(h->st); delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
@@ -308,6 +309,7 @@ extern "C" int slsqp_update_linear_cost(slsqp_handle *h, const double *q, int lo
 
 // ---- small mask kernels ------------------------------------------------------------------------------------
 __global__ void k_fill_int(int *p, int v, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+__global__ void k_fill_doubles(double *p, double v, size_t n) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v; }
 __global__ void k_negate(const double *x, double *y, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) y[i] = -x[i]; }
 // after a QP: instances whose QP failed drop out (forward_solve -> False, fast_SLS_jit.py:461-464)
 __global__ void k_post_qp(int B, const int *status, int *alive, int *infeas) {
@@ -324,7 +326,7 @@ __global__ void k_post_conv(int B, int rti, const int *conv, int *alive, int *ma
         else m = 1;
     }
     mask[b] = m;
-    if (m) { itnum[b] += 1; stale[b] &= ~2; atomicAdd(counter, 1); }   // the sweep that follows rewrites this instance's K
+    if (m) { itnum[b] += 1; stale[b] = (stale[b] & ~2) | 8; atomicAdd(counter, 1); }   // the sweep that follows rewrites this instance's K and beta
 }
 __global__ void k_finish(int B, int rti, const int *alive, const int *infeas, int *success, const int *active, int *pending_reset) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -336,14 +338,15 @@ __global__ void k_finish(int B, int rti, const int *alive, const int *infeas, in
 // _finish_failure (fast_SLS_jit.py:334-341) resets the solver AFTER the result dict has been built: the reset (eta, eta_f,
 // iteration_number -> 0; bounds and linear cost are rewritten by the caller's next update anyway) is applied at the top of the
 // instance's next solve, so that slsqp_get still returns the failed call's arrays.
-__global__ void k_apply_pending_reset(int B, int *pending, const int *active, int *itnum, double *eta, size_t neta, double *eta_f, size_t netaf) {
+__global__ void k_apply_pending_reset(int B, int *pending, const int *active, int *itnum, double *eta, size_t neta, double *eta_f, size_t netaf, int *stale) {
     const int b = blockIdx.x;
     if (!pending[b] || (active && !active[b])) return;
     for (size_t o = threadIdx.x; o < neta; o += blockDim.x) eta[(size_t)b * neta + o] = 0.0;
     for (size_t o = threadIdx.x; o < netaf; o += blockDim.x) eta_f[(size_t)b * netaf + o] = 0.0;
     __syncthreads();
-    if (threadIdx.x == 0) { itnum[b] = 0; pending[b] = 0; }
+    if (threadIdx.x == 0) { itnum[b] = 0; pending[b] = 0; stale[b] &= ~16; }
 }
+__global__ void k_reset_stale(int *p, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = (p[i] & 8) | 3; }   // eta, K: zero on demand; beta keeps its state
 __global__ void k_and_int(int *p, int v, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] &= v; }
 // instances whose `bit` is set in stale[]: zero their slice of arr1 (and arr2), then clear the bit (last use decides: clear_bit)
 __global__ void k_zero_stale(int *stale, int bit, double *arr1, size_t n1, double *arr2, size_t n2) {
@@ -493,6 +496,7 @@ static int launch_sweep_shared_t(slsqp_handle *h, const SweepArgs &a) {
     HIPCHK(hipGetLastError());
     return 0;
 }
+static bool sweep_shared_allowed() { static const bool v = getenv("SLSQP_SWEEP_SHARED") ? atoi(getenv("SLSQP_SWEEP_SHARED")) != 0 : true; return v; }
 // shared_cols: every column's eta is the same (first fast-SLS iteration after initialize_backoff): one Riccati recursion per instance
 static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, const double *eta_f, double eps, bool shared_cols = false) {
     SweepArgs a;
@@ -507,8 +511,7 @@ static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, cons
         HIPCHK(hipGetLastError());
         return 0;
     }
-    static const bool allow_shared = getenv("SLSQP_SWEEP_SHARED") ? atoi(getenv("SLSQP_SWEEP_SHARED")) != 0 : true;
-    if (shared_cols && allow_shared) {
+    if (shared_cols && sweep_shared_allowed()) {
 #define X(NX_, NU_) if (h->d.nx == NX_ && h->d.nu == NU_) return launch_sweep_shared_t<NX_, NU_>(h, a);
         SLSQP_DIM_LIST
 #undef X
@@ -548,12 +551,21 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     if (active) hipLaunchKernelGGL(k_copy_int, dim3(gb), dim3(256), 0, h->st, active, h->alive, B);
     else hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->alive, 1, B);
     hipLaunchKernelGGL(k_apply_pending_reset, dim3(B), dim3(256), 0, h->st, B, h->pending_reset, active, h->itnum, h->eta, (size_t)d.N * d.N * d.ni, h->eta_f,
-                       (size_t)(d.N + 1) * d.ni_f);
+                       (size_t)(d.N + 1) * d.ni_f, h->stale);
     hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->infeas, 0, B);
     hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->success, 0, B);
     {   // initialize_backoff at the top of every solve (fast_SLS_jit.py:281,299)
-        InitBackoffArgs ia{B, d.N, d.nx, d.nu, o.eps_backoff, active, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u};
-        hipLaunchKernelGGL(k_init_backoff, dim3(B), dim3(256), 0, h->st, ia);
+        // the first solve of a handle fills beta for every instance (also the ones outside `active`: later calls rely on it)
+        InitBackoffArgs ia{B, d.N, d.nx, d.nu, o.eps_backoff, h->beta_inited ? active : nullptr, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->beta_inited ? 0 : 1};
+        if (!h->beta_inited && active) {   // ... but their back-off arrays must stay untouched: two launches then
+            InitBackoffArgs ib = ia; ib.run = nullptr;
+            InitBackoffArgs ic = ia; ic.run = active; ic.fill_beta = 0;
+            hipLaunchKernelGGL(k_fill_doubles, dim3(1024), dim3(256), 0, h->st, h->beta, o.eps_backoff, (size_t)B * d.N * d.N * d.ni);
+            hipLaunchKernelGGL(k_fill_doubles, dim3(1024), dim3(256), 0, h->st, h->beta_f, o.eps_backoff, (size_t)B * (d.N + 1) * d.ni_f);
+            (void)ib;
+            hipLaunchKernelGGL(k_init_backoff, dim3(B), dim3(256), 0, h->st, ic);
+        } else hipLaunchKernelGGL(k_init_backoff, dim3(B), dim3(256), 0, h->st, ia);
+        h->beta_inited = true;
     }
     double acc_qp = 0, acc_sw = 0;
     for (int i = 0; i < steps; i++) {
@@ -561,12 +573,13 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         if (launch_qp(h, h->alive, &o, (i > 0 || o.warm_start) ? 1 : 0, nullptr, 0, 1, i > 0 ? 1 : 0)) return -1;
         HIPCHK(hipEventRecord(h->ev[2], h->st));
         hipLaunchKernelGGL(k_post_qp, dim3(gb), dim3(256), 0, h->st, B, h->status, h->alive, h->infeas);
-        EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff, h->stale};
+        EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff, h->stale, (i == 0 && sweep_shared_allowed()) ? 1 : 0};
         hipLaunchKernelGGL(k_eta, dim3(B), dim3(256), 0, h->st, ea);
         ConvArgs ca{B, h->n, h->primal, h->prev_primal, h->has_prev, h->alive, h->conv, o.conv_tol};
         hipLaunchKernelGGL(k_conv, dim3(B), dim3(64), 0, h->st, ca);
         HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), h->st));
         hipLaunchKernelGGL(k_post_conv, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->conv, h->alive, h->mask, h->success, h->itnum, h->counter, h->stale);
+        if (i == 0) hipLaunchKernelGGL(k_fix_beta, dim3(B), dim3(256), 0, h->st, d.N, d.ni, d.ni_f, o.eps_backoff, active, h->mask, h->stale, h->beta, h->beta_f);
         HIPCHK(hipEventRecord(h->ev[3], h->st));
         if (launch_sweep(h, h->mask, h->eta, h->eta_f, o.eps_backoff, /* beta == eps for every column right after initialize_backoff */ i == 0)) return -1;
         HIPCHK(hipEventRecord(h->ev[4], h->st));
@@ -617,8 +630,10 @@ extern "C" int slsqp_get(slsqp_handle *h, const char *name, void *out, int loc) 
     const size_t bytes = it->second.second * (size_t)h->B;
     {   // arrays that slsqp_reset only marked stale
         const slsqp_dims &d = h->d;
-        if (!strcmp(name, "eta") || !strcmp(name, "eta_f"))
+        if (!strcmp(name, "eta") || !strcmp(name, "eta_f")) {
             hipLaunchKernelGGL(k_zero_stale, dim3(h->B), dim3(256), 0, h->st, h->stale, 1, h->eta, (size_t)d.N * d.N * d.ni, h->eta_f, (size_t)(d.N + 1) * d.ni_f);
+            hipLaunchKernelGGL(k_eta_broadcast, dim3(h->B), dim3(256), 0, h->st, d.N, d.ni, d.ni_f, h->stale, h->eta, h->eta_f);
+        }
         else if (!strcmp(name, "K"))
             hipLaunchKernelGGL(k_zero_stale, dim3(h->B), dim3(256), 0, h->st, h->stale, 2, h->K, (size_t)d.N * (d.N + 1) * d.nu * d.nx, (double *)nullptr, (size_t)0);
     }
@@ -650,7 +665,7 @@ extern "C" int slsqp_reset(slsqp_handle *h) {
     const size_t B = h->B;
     // eta, eta_f and K (1.5 GB at rocket B = 4096) are not cleared here: every entry the device reads is rewritten first (k_eta before the
     // sweep, the sweep before anything reads K), so they are only marked stale and zeroed on demand when slsqp_get asks for them
-    hipLaunchKernelGGL(k_fill_int, dim3((h->B + 255) / 256), dim3(256), 0, h->st, h->stale, 3, h->B);
+    hipLaunchKernelGGL(k_reset_stale, dim3((h->B + 255) / 256), dim3(256), 0, h->st, h->stale, h->B);
     HIPCHK(hipMemsetAsync(h->itnum, 0, sizeof(int) * B, h->st));
     HIPCHK(hipMemsetAsync(h->pending_reset, 0, sizeof(int) * B, h->st));
     HIPCHK(hipMemsetAsync(h->q, 0, sizeof(double) * B * h->n, h->st));
@@ -983,7 +998,7 @@ extern "C" int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta
     const size_t B = h->B;
     if (put(h, h->eta, eta, sizeof(double) * B * d.N * d.N * d.ni, loc)) return -1;
     if (put(h, h->eta_f, eta_f, sizeof(double) * B * (d.N + 1) * d.ni_f, loc)) return -1;
-    hipLaunchKernelGGL(k_fill_int, dim3((h->B + 255) / 256), dim3(256), 0, h->st, h->stale, 0, h->B);   // eta given by the caller, K written for every instance
+    hipLaunchKernelGGL(k_fill_int, dim3((h->B + 255) / 256), dim3(256), 0, h->st, h->stale, 8, h->B);   // eta given by the caller, K and beta written for every instance
     HIPCHK(hipEventRecord(h->ev[0], h->st));
     if (launch_sweep(h, nullptr, h->eta, h->eta_f, 1e-10)) return -1;
     HIPCHK(hipEventRecord(h->ev[1], h->st));

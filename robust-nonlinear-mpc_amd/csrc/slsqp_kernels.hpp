@@ -1278,25 +1278,59 @@ __global__ void k_set_bounds(BoundsArgs a) {
 // ------------------------------------------------------------------------------------------------
 // evaluate_dual_eta (fast_SLS_jit.py:475-487)
 // ------------------------------------------------------------------------------------------------
-struct EtaArgs { int B, N, NX, NI, NIF; const double *dual, *beta, *beta_f; const int *run; double *eta, *eta_f; double eps; int *stale; };
+// stale[b] bits: 1 eta / eta_f and 2 K hold values from before the last slsqp_reset (zeroed on demand by slsqp_get); 8 beta / beta_f hold a
+// sweep's values (not the eps of initialize_backoff); 16 eta / eta_f hold only column 0 of a first fast-SLS iteration (broadcast on demand)
+struct EtaArgs { int B, N, NX, NI, NIF; const double *dual, *beta, *beta_f; const int *run; double *eta, *eta_f; double eps; int *stale; int first_iter; };
 __global__ void k_eta(EtaArgs a) {
     const int b = blockIdx.x;
     if (a.run && !a.run[b]) return;
     const int SR = a.NX + a.NI, mb = a.N * SR + a.NIF;
-    if (a.stale && threadIdx.x == 0) a.stale[b] &= ~1;   // every entry with j <= k is rewritten below; the others are never written by anyone (zero)
     const double *du = a.dual + (size_t)b * mb;
-    const double *be = a.beta + (size_t)b * a.N * a.N * a.NI;
     double *et = a.eta + (size_t)b * a.N * a.N * a.NI;
+    double *ef = a.eta_f + (size_t)b * (a.N + 1) * a.NIF;
+    if (a.first_iter) {
+        // first iteration of a solve: beta = eps in every entry (initialize_backoff), so eta[k,j] = mu_k / (2 sqrt(eps)) for every j <= k.  Only
+        // column 0 is written -- all the shared Riccati recursion reads (k_sweep_ric1); slsqp_get broadcasts it when the array is asked for.
+        const double s0 = 2.0 * sqrt(a.eps);
+        for (int o = threadIdx.x; o < a.N * a.NI; o += blockDim.x) { const int i = o % a.NI, k = o / a.NI; et[((size_t)k * a.N) * a.NI + i] = du[k * SR + a.NX + i] / s0; }
+        for (int o = threadIdx.x; o < a.NIF; o += blockDim.x) ef[o] = du[a.N * SR + o] / s0;
+        if (a.stale && threadIdx.x == 0) a.stale[b] = (a.stale[b] & ~1) | 16;
+        return;
+    }
+    if (a.stale && threadIdx.x == 0) a.stale[b] &= ~(1 | 16);   // every entry with j <= k is rewritten below; the others are never written by anyone (zero)
+    const double *be = a.beta + (size_t)b * a.N * a.N * a.NI;
     for (int o = threadIdx.x; o < a.N * a.N * a.NI; o += blockDim.x) {
         const int i = o % a.NI, j = (o / a.NI) % a.N, k = o / (a.NI * a.N);
         if (j <= k) et[o] = du[k * SR + a.NX + i] / (2.0 * sqrt(fmax(be[o], a.eps)));
     }
     const double *bf = a.beta_f + (size_t)b * (a.N + 1) * a.NIF;
-    double *ef = a.eta_f + (size_t)b * (a.N + 1) * a.NIF;
     for (int o = threadIdx.x; o < (a.N + 1) * a.NIF; o += blockDim.x) {
         const int i = o % a.NIF;
         ef[o] = du[a.N * SR + i] / (2.0 * sqrt(fmax(bf[o], a.eps)));
     }
+}
+// eta[k,j] = eta[k,0] (1 <= j <= k), eta_f[j] = eta_f[0] for the instances whose arrays hold only column 0
+__global__ void k_eta_broadcast(int N, int NI, int NIF, int *stale, double *eta, double *eta_f) {
+    const int b = blockIdx.x;
+    if (!(stale[b] & 16)) return;
+    double *et = eta + (size_t)b * N * N * NI, *ef = eta_f + (size_t)b * (N + 1) * NIF;
+    for (int o = threadIdx.x; o < N * N * NI; o += blockDim.x) {
+        const int i = o % NI, j = (o / NI) % N, k = o / (NI * N);
+        if (j >= 1 && j <= k) et[o] = et[((size_t)k * N) * NI + i];
+    }
+    for (int o = threadIdx.x; o < N * NIF; o += blockDim.x) ef[NIF + o] = ef[o % NIF];
+    __syncthreads();
+    if (threadIdx.x == 0) stale[b] &= ~16;
+}
+// instances of this call that the first iteration does not sweep (failed QP, or quirk q5) but whose beta still holds an earlier solve's
+// values: initialize_backoff's eps, which the solve start no longer writes for everybody (1.1 GB per 4096 rocket instances)
+__global__ void k_fix_beta(int N, int NI, int NIF, double eps, const int *active, const int *mask, int *stale, double *beta, double *beta_f) {
+    const int b = blockIdx.x;
+    if ((active && !active[b]) || mask[b] || !(stale[b] & 8)) return;
+    for (int o = threadIdx.x; o < N * N * NI; o += blockDim.x) beta[(size_t)b * N * N * NI + o] = eps;
+    for (int o = threadIdx.x; o < (N + 1) * NIF; o += blockDim.x) beta_f[(size_t)b * (N + 1) * NIF + o] = eps;
+    __syncthreads();
+    if (threadIdx.x == 0) stale[b] &= ~8;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1998,14 +2032,16 @@ __global__ void k_tighten(TightenArgs a) {
 }
 
 // initialize_backoff (fast_SLS_jit.py:444-454)
-struct InitBackoffArgs { int B, N, NX, NU; double eps; const int *run; double *beta, *beta_f, *backoff, *backoff_f, *backoff_x, *backoff_u; };
+struct InitBackoffArgs { int B, N, NX, NU; double eps; const int *run; double *beta, *beta_f, *backoff, *backoff_f, *backoff_x, *backoff_u; int fill_beta; };
 __global__ void k_init_backoff(InitBackoffArgs a) {
     const int b = blockIdx.x;
     if (a.run && !a.run[b]) return;
     const int NZ = a.NX + a.NU, NI = 2 * NZ, NIF = 2 * a.NX, N = a.N;
     const double sq = sqrt(a.eps);
-    for (int o = threadIdx.x; o < N * N * NI; o += blockDim.x) a.beta[(size_t)b * N * N * NI + o] = a.eps;
-    for (int o = threadIdx.x; o < (N + 1) * NIF; o += blockDim.x) a.beta_f[(size_t)b * (N + 1) * NIF + o] = a.eps;
+    if (a.fill_beta) {   // only the handle's first solve: afterwards beta is eps wherever no sweep wrote, and k_fix_beta repairs the rest
+        for (int o = threadIdx.x; o < N * N * NI; o += blockDim.x) a.beta[(size_t)b * N * N * NI + o] = a.eps;
+        for (int o = threadIdx.x; o < (N + 1) * NIF; o += blockDim.x) a.beta_f[(size_t)b * (N + 1) * NIF + o] = a.eps;
+    }
     for (int o = threadIdx.x; o < N * NI; o += blockDim.x) a.backoff[(size_t)b * N * NI + o] = N * sq;
     for (int o = threadIdx.x; o < NIF; o += blockDim.x) a.backoff_f[(size_t)b * NIF + o] = (N + 1) * sq;
     for (int o = threadIdx.x; o < (N + 1) * a.NX; o += blockDim.x) a.backoff_x[(size_t)b * (N + 1) * a.NX + o] = 0.0;

@@ -326,7 +326,7 @@ __global__ void k_post_conv(int B, int rti, const int *conv, int *alive, int *ma
         else m = 1;
     }
     mask[b] = m;
-    if (m) { itnum[b] += 1; stale[b] = (stale[b] & ~2) | 8; atomicAdd(counter, 1); }   // the sweep that follows rewrites this instance's K and beta
+    if (m) { itnum[b] += 1; stale[b] = (stale[b] & ~(2 | 32)) | 8; atomicAdd(counter, 1); }   // the sweep that follows rewrites this instance's K and beta
 }
 __global__ void k_finish(int B, int rti, const int *alive, const int *infeas, int *success, const int *active, int *pending_reset) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -489,7 +489,7 @@ static int launch_sweep_t(slsqp_handle *h, const SweepArgs &a) {
 }
 template <int NX, int NU>
 static int launch_sweep_shared_t(slsqp_handle *h, const SweepArgs &a) {
-    SweepSharedArgs aa{a, h->Kc, h->Aclc};
+    SweepSharedArgs aa{a, h->Kc, h->Aclc, h->stale};
     const size_t lds_ric = sizeof(double) * sweep_lds_doubles<NX, NU>(), lds_prop = sizeof(double) * sweep_prop_lds_doubles<NX, NU>();
     hipLaunchKernelGGL((k_sweep_ric1<NX, NU>), dim3(h->B), dim3(64), lds_ric, h->st, aa);
     hipLaunchKernelGGL((k_sweep_prop<NX, NU>), dim3(h->B * (h->d.N + 1)), dim3(64), lds_prop, h->st, aa);
@@ -634,8 +634,10 @@ extern "C" int slsqp_get(slsqp_handle *h, const char *name, void *out, int loc) 
             hipLaunchKernelGGL(k_zero_stale, dim3(h->B), dim3(256), 0, h->st, h->stale, 1, h->eta, (size_t)d.N * d.N * d.ni, h->eta_f, (size_t)(d.N + 1) * d.ni_f);
             hipLaunchKernelGGL(k_eta_broadcast, dim3(h->B), dim3(256), 0, h->st, d.N, d.ni, d.ni_f, h->stale, h->eta, h->eta_f);
         }
-        else if (!strcmp(name, "K"))
+        else if (!strcmp(name, "K")) {
             hipLaunchKernelGGL(k_zero_stale, dim3(h->B), dim3(256), 0, h->st, h->stale, 2, h->K, (size_t)d.N * (d.N + 1) * d.nu * d.nx, (double *)nullptr, (size_t)0);
+            hipLaunchKernelGGL(k_K_broadcast, dim3(h->B), dim3(256), 0, h->st, d.N, d.nu * d.nx, h->stale, h->Kc, h->K);
+        }
     }
     HIPCHK(hipMemcpyAsync(out, it->second.first, bytes, loc == SLSQP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->st));
     HIPCHK(hipStreamSynchronize(h->st));

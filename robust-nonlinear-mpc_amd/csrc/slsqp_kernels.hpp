@@ -1279,7 +1279,8 @@ __global__ void k_set_bounds(BoundsArgs a) {
 // evaluate_dual_eta (fast_SLS_jit.py:475-487)
 // ------------------------------------------------------------------------------------------------
 // stale[b] bits: 1 eta / eta_f and 2 K hold values from before the last slsqp_reset (zeroed on demand by slsqp_get); 8 beta / beta_f hold a
-// sweep's values (not the eps of initialize_backoff); 16 eta / eta_f hold only column 0 of a first fast-SLS iteration (broadcast on demand)
+// sweep's values (not the eps of initialize_backoff); 16 eta / eta_f hold only column 0 of a first fast-SLS iteration (broadcast on demand);
+// 32 K is still in its compact form Kc (shared Riccati recursion; broadcast on demand)
 struct EtaArgs { int B, N, NX, NI, NIF; const double *dual, *beta, *beta_f; const int *run; double *eta, *eta_f; double eps; int *stale; int first_iter; };
 __global__ void k_eta(EtaArgs a) {
     const int b = blockIdx.x;
@@ -1321,6 +1322,19 @@ __global__ void k_eta_broadcast(int N, int NI, int NIF, int *stale, double *eta,
     for (int o = threadIdx.x; o < N * NIF; o += blockDim.x) ef[NIF + o] = ef[o % NIF];
     __syncthreads();
     if (threadIdx.x == 0) stale[b] &= ~16;
+}
+// K[k,j] = Kc[k] (j <= k) for the instances whose K array was not written by the shared sweep (stale bit 32)
+__global__ void k_K_broadcast(int N, int NUNX, int *stale, const double *Kc, double *K) {
+    const int b = blockIdx.x;
+    if (!(stale[b] & 32)) return;
+    const double *kc = Kc + (size_t)b * N * NUNX;
+    double *kg = K + (size_t)b * N * (N + 1) * NUNX;
+    for (int o = threadIdx.x; o < N * (N + 1) * NUNX; o += blockDim.x) {
+        const int e = o % NUNX, j = (o / NUNX) % (N + 1), k = o / (NUNX * (N + 1));
+        kg[o] = (j <= k) ? kc[(size_t)k * NUNX + e] : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) stale[b] &= ~32;
 }
 // instances of this call that the first iteration does not sweep (failed QP, or quirk q5) but whose beta still holds an earlier solve's
 // values: initialize_backoff's eps, which the solve start no longer writes for everybody (1.1 GB per 4096 rocket instances)
@@ -1766,6 +1780,7 @@ __global__ __launch_bounds__(64) void k_sweep_gen(SweepGenArgs ga) {
 struct SweepSharedArgs {
     SweepArgs s;
     double *Kc, *Aclc;         // scratch (B,N,NU,NX), (B,N,NX,NX)
+    int *stale;                // bit 32 set by k_sweep_ric1: K[k,j] = Kc[k] (j <= k) not written out yet (slsqp_get broadcasts it on demand)
 };
 template <int NX, int NU>
 __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep_ric1(SweepSharedArgs aa) {
@@ -1803,6 +1818,7 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep_ric1(SweepSh
         const double *e = eta + ((size_t)k * N + j) * NI;
         rC = e[lz] + e[NZ + lz] + regd;
     };
+    if (lane == 0 && aa.stale) aa.stale[b] = (aa.stale[b] & ~2) | 32;
     fetch(N - 1);
     for (int k = N - 1; k >= 0; k--) {
 #pragma unroll
@@ -1917,7 +1933,6 @@ __global__ __launch_bounds__(64, 4) void k_sweep_prop(SweepSharedArgs aa) {
     double *sAcl = p; p += NX * NX; double *sPhi = p; p += NX * NX; double *sPhi2 = p; p += NX * NX;
     double *sK = p; p += NX * NU; double *sPu = p; p += NU * NW;
     const double *gKc = aa.Kc + (size_t)b * N * NU * NX, *gAc = aa.Aclc + (size_t)b * N * NX * NX;
-    double *gK = a.K + (size_t)b * N * (N + 1) * NU * NX;
     double *beta = a.beta + (size_t)b * N * N * NI, *beta_f = a.beta_f + (size_t)b * (N + 1) * NIF;
     const double *Eg = a.E + (a.E_per_instance ? (size_t)b * (N + 1) * NX * NW : 0) + (size_t)j * NX * NW;
 #pragma unroll
@@ -1936,11 +1951,10 @@ __global__ __launch_bounds__(64, 4) void k_sweep_prop(SweepSharedArgs aa) {
     };
     if (j < N) fetch2(j);
     for (int k = j; k < N; k++) {
-        double *Kg = gK + ((size_t)k * (N + 1) + j) * NU * NX;
 #pragma unroll
         for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < NX * NX) sAcl[o] = rA[r]; }
 #pragma unroll
-        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) { sK[o] = rK[r]; Kg[o] = rK[r]; } }   // K[k,j] = K_k of the result
+        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) sK[o] = rK[r]; }
         wla::wsync();
         if (k + 1 < N) fetch2(k + 1);
 #if SWEEP_MFMA

@@ -187,6 +187,11 @@ def test_fastsls_step_vs_oracle(model, rti):
         assert relerr(out["backoff_f"][b], ref["backoff_f"]) < 1e-6
         assert relerr(out["backoff_x"][b], ref["backoff_x"]) < 1e-6
         assert relerr(out["beta"][b], ref["beta"]) < 1e-6
+        assert relerr(out["beta_f"][b], ref["beta_f"]) < 1e-6
+        # eta, eta_f and K: full (N,N,ni) / (N+1,ni_f) / (N,N+1,nu,nx) arrays as the reference returns them -- after a single fast-SLS iteration the
+        # device holds only column 0 of eta and the compact K_k of the shared Riccati recursion, and slsqp_get broadcasts them on demand
+        assert relerr(out["eta"][b], ref["eta"]) < 1e-5 and relerr(out["eta_f"][b], ref["eta_f"]) < 1e-5
+        assert relerr(out["K"][b], ref["K"]) < 1e-6
         assert np.allclose(out["primal_x"][b], ref["primal_x"], rtol=1e-6, atol=1e-7)
         assert np.allclose(out["primal_u"][b], ref["primal_u"], rtol=1e-6, atol=1e-7)
         assert abs(out["cost_nominal"][b] - ref["cost_nominal"]) < 1e-6 * max(1.0, abs(ref["cost_nominal"]))

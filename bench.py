@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--qp-eps", type=float, default=None, help="interior-point tolerance before the polish (default: the library's 1e-6)")
     ap.add_argument("--precision", type=int, default=0, help="0: fp64 (headline); 1: mixed fp32 factorisation / fp64 residuals (secondary figure)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--x0-scale", type=float, default=None, help="closed loop: initial state = hover + s (script x0 - hover); default 0.3 for the rocket (1.0 = the script's own "
+                    "state: the nominal initialiser then runs its two-stage continuation)")
     return ap.parse_args()
 
 
@@ -114,9 +116,9 @@ class ClosedLoopSlices:
         self.step_no = 0
         self.stats = [[] for _ in self.cl]       # per slice: list over steps of qp_stats (b,2,8)
 
-    def setup(self, x0):
+    def setup(self, x0, continuation=1):
         import numpy as np
-        self._threads(lambda k: self.cl[k].reset(np.tile(x0, (self.cl[k].B, 1)), solve_nominal=True))
+        self._threads(lambda k: self.cl[k].reset(np.tile(x0, (self.cl[k].B, 1)), solve_nominal=True, continuation=continuation))
         return np.concatenate([cl.nlp_status for cl in self.cl])
 
     def _threads(self, fn):
@@ -318,9 +320,11 @@ def main():
     out = {}
     if args.workload == "closed_loop":
         seeds = rank * B + np.arange(B)
-        x0 = m.x_ref + X0_SCALE[args.model] * (m.extra["x0"] - m.x_ref) if "x0" in m.extra else m.x_ref + 0.02 * (m.x_ub - m.x_lb)
+        x0_scale = X0_SCALE[args.model] if args.x0_scale is None else args.x0_scale
+        cont = 2 if x0_scale > 0.6 else 1
+        x0 = m.x_ref + x0_scale * (m.extra["x0"] - m.x_ref) if "x0" in m.extra else m.x_ref + 0.02 * (m.x_ub - m.x_lb)
         dev = ClosedLoopSlices(m, N, seeds, args.slices, args.warmup + args.steps, local_rank, tune)
-        nlp = dev.setup(x0)
+        nlp = dev.setup(x0, cont)
         dev.run(args.warmup, collect_stats=False)
         gather(torch.cat([dev.fetch_device("x_meas", (m.nx,)), dev.fetch_device("u0", (m.nu,))], dim=1))     # warm the gather path
         barrier()
@@ -331,7 +335,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         workload = (f"{args.model} N={N} batch={B}/GPU closed-loop Monte-Carlo, one slsqp_cl_step per step (shift + reset, linearise, fast-SLS RTI: 2 QP solves + 1 SLS "
-                    f"sweep per instance, nominal update, plant + seeded noise); x0 = hover + {X0_SCALE[args.model]} (script x0 - hover), nominal from the GPU "
+                    f"sweep per instance, nominal update, plant + seeded noise); x0 = hover + {x0_scale} (script x0 - hover), nominal from the GPU "
                     f"initialiser (untimed); timed steps = closed-loop steps {args.warmup}..{args.warmup + args.steps - 1}")
         qstat = qp_statistics([np.concatenate([dev.stats[k][s] for k in range(len(dev.cl))]) for s in range(args.steps)])
         succ = dev.get("scp_success", (), np.int32)
@@ -404,7 +408,7 @@ def main():
                 # duration of a launch includes the time it shares the GPU with the other slices' launches
                 if n_sl > 1 and args.workload == "closed_loop":
                     one = ClosedLoopSlices(m, N, seeds, 1, args.warmup + args.steps, local_rank, tune)
-                    one.setup(x0)
+                    one.setup(x0, cont)
                     one.run(args.warmup, collect_stats=False)
                     torch.cuda.synchronize()
                     one.kernel_timing()

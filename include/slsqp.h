@@ -64,7 +64,7 @@ typedef struct {
     int want_K;          /* accepted and ignored: K (N,N+1,nu,nx) is always kept (the propagation of the sweep reads it back) */
     int warm_start;      /* 1 (default): the first QP of a call first tries an active-set polish from the instance's previous
                             certified solution (KKT-verified, falls back to the interior point); later QPs of a call always do */
-    int warm_rounds;     /* active-set correction rounds a warm attempt may use before falling back (default 10) */
+    int warm_rounds;     /* active-set correction rounds a warm attempt may use before falling back (default 20) */
     int max_scp_iter;    /* MAX_ITER_SCP (100, SCP_SLS_jit.py:47): cap of the SCP loop of slsqp_cl_step in converge mode (rti <= 0) */
     double scp_eps;      /* epsilon_convergence (1e-10, SCP_SLS_jit.py:29): SCP converged when |delta_vec|inf < scp_eps */
     int precision;       /* 0 (default): fp64 throughout.  1: mixed -- block factorisations, stored inverses and substitutions in fp32,
@@ -72,7 +72,7 @@ typedef struct {
                             that do not certify are solved again in fp64 (BASELINE config 3, "fp32 vs fp64") */
     int as_first;        /* 1 (default): a cold QP solve first runs the active-set iteration from the empty set (round 0 = the equality-constrained
                             optimum), certificate-checked like every polish, and only falls back to the interior point when that fails */
-    int as_rounds;       /* correction rounds such an attempt may use (default 12) */
+    int as_rounds;       /* correction rounds such an attempt may use (default 24) */
     int as_max_viol;     /* an active-set attempt is abandoned when one of its solves leaves more violated bounds than this (default 64), or more
                             than twice the previous round's + 8: a set that pins both ends of a dynamics row makes the solve blow up */
     int ipm_restart;     /* 1 (default): QPs after the first of a fast-SLS call (same A, B, q, tightened bounds) whose warm active-set attempt

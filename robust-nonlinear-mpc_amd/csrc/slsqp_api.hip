@@ -384,24 +384,25 @@ __global__ void k_join_y(int B, int mb, int nx, const double *dual, const double
 template <int NX, int NU>
 static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter, bool mx) {
     // the fp64 kernels' LDS also holds two n-vectors of the phase logic between the sweeps (phase_update, fused look)
-    const size_t lds = mx ? QpLdsMx<NX, NU>::BYTES : sizeof(double) * (size_t)std::max(qp_lds_doubles<NX, NU>(h->d.N), 2 * h->n + 8);
+    const size_t lds = std::max(mx ? QpLdsMx<NX, NU>::BYTES : sizeof(double) * (size_t)qp_lds_doubles<NX, NU>(h->d.N), sizeof(double) * (size_t)(2 * h->n + 8));
     const dim3 grid(h->B), blk(64);
     // every instance needs 1 (start) + 2 per interior-point iteration + (1 + n_refine) per polish round ticks, after at most warm_rounds + as_rounds
     // active-set rounds of the attempts that precede the interior point
     const int max_ticks = 1 + 2 * max_iter + 3 + 2 * 10 + 8 + 2 + 16 + 2 * (a.warm_rounds + a.as_rounds + 2);
     static const bool persistent = getenv("SLSQP_PERSISTENT") ? atoi(getenv("SLSQP_PERSISTENT")) != 0 : true;
-    if (!mx && persistent) {
+    if (persistent) {
         // one launch per QP solve: every wave runs its instance to completion (k_qp_solve)
         const bool timed = h->time_kernels && h->n_kev + 2 <= (int)h->kev.size();
         if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
-        hipLaunchKernelGGL((k_qp_solve<NX, NU>), grid, blk, lds, h->st, a, max_ticks);
+        if (mx) hipLaunchKernelGGL((k_qp_solve<NX, NU, true>), grid, blk, lds, h->st, a, max_ticks);
+        else hipLaunchKernelGGL((k_qp_solve<NX, NU, false>), grid, blk, lds, h->st, a, max_ticks);
         if (timed) { hipEventRecord(h->kev[h->n_kev + 1], h->st); h->n_kev += 2; }
         HIPCHK(hipGetLastError());
         return 0;
     }
     HIPCHK(hipMemsetAsync(a.n_active, 0, sizeof(int), h->st));
     hipLaunchKernelGGL((k_phase<NX, NU>), grid, blk, 0, h->st, a, 1);
-    // tick kernels (mixed precision; fp64 with SLSQP_PERSISTENT=0): poll the number of unfinished instances every few ticks instead of
+    // tick kernels (SLSQP_PERSISTENT=0): poll the number of unfinished instances every few ticks instead of
     // running the worst case
     static const int first_burst = getenv("SLSQP_BURST0") ? atoi(getenv("SLSQP_BURST0")) : 12, tail_burst = getenv("SLSQP_BURST") ? atoi(getenv("SLSQP_BURST")) : 3;
     int tick = 0, active = 1;

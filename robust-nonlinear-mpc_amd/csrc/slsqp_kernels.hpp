@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(64) void k_ne_bwd_phase(QpArgs a) {
 #ifndef QP_PERSIST_WAVES_PER_SIMD
 #define QP_PERSIST_WAVES_PER_SIMD 3
 #endif
-template <int NX, int NU>
+template <int NX, int NU, bool MX = false>     // MX: the mixed-precision sweeps (ne_forward_mx / ne_backward_mx, section 2.4 of DESIGN.md), same loop and phase logic
 __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpArgs a, int max_ticks) {
     int b = blockIdx.x, lane = threadIdx.x;
     if (b >= a.B || (a.run && !a.run[b])) return;
@@ -1197,7 +1197,9 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
         const FwdPlan fp = fwd_plan(st, phase, a.N);
         const bool factor = fp.factor;
         double bmax = 0.0;
-        const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, nullptr, &bmax, fp.k0, fp.ks);
+        int f;
+        if constexpr (MX) f = ne_forward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, &bmax, fp.k0);
+        else f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, nullptr, &bmax, fp.k0, fp.ks);
         if (lane == 0) {
             if (phase == P_POL1 || phase == P_POL2) st->pbox = bmax;
             st->ticks += 1.0;
@@ -1210,7 +1212,8 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
 #endif
         asm volatile("" : "+s"(b));
         asm volatile("" : "+v"(lane));
-        ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
+        if constexpr (MX) ne_backward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
+        else ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
         wla::wsync_mem();
         QSTAMP(c_bwd);
         asm volatile("" : "+s"(b));

@@ -142,6 +142,10 @@ class BatchedFastSLS:
             self.h = None
 
     def __del__(self):
+        # not at interpreter shutdown: the HIP runtime may already be gone then, and calling into it aborts the process
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

@@ -5,12 +5,16 @@ import csv, glob, json, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
 build = sys.argv[3] if len(sys.argv) > 3 else "?"
 cmd = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 2 --warmup 1 --no-cpu --no-secondary"
+tail_n = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # the bench's timed region = the last tail_n launches of the dominant kernel
+per_disp = collections.defaultdict(lambda: collections.defaultdict(dict))
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             k = r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+            d = per_disp[k][r["Counter_Name"]]
+            d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
 out = {}
 for k, v in acc.items():
     nf, nw = max(1, len(calls[k]["FETCH_SIZE"])), max(1, len(calls[k]["WRITE_SIZE"]))
@@ -20,5 +24,14 @@ res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
 for kn in ("k_ne_fwd", "k_qp_solve", "k_sweep", "k_lin_jac"):
     if kn in out:
         res[kn + "_bytes_per_launch"] = out[kn]["fetch_bytes_per_launch_x2"] + out[kn]["write_bytes_per_launch"]
+if tail_n > 0 and "k_qp_solve" in per_disp:
+    # same launches as bench.py's roofline averages: the last tail_n dispatches of k_qp_solve (the earlier ones belong to the untimed set-up)
+    tot = 0.0
+    for cn, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        dd = per_disp["k_qp_solve"].get(cn, {})
+        last = sorted(dd)[-tail_n:]
+        tot += mult * 1024.0 * sum(dd[i] for i in last) / max(1, len(last))
+    res["k_qp_solve_bytes_per_launch_timed_region"] = tot
+    res["timed_region_launches"] = tail_n
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps(res)[:1500])

@@ -184,20 +184,10 @@ DYN_HD void ddyn(const T *X, const T *U, T *Xp) {
     for (int i = 0; i < NX; i++) Xp[i] = X[i] + T(1.0 / 6.0) * (acc[i] + k[i]) * h;
 }
 
-// one column of [A B] = d ddyn / d (x,u)_dir by forward-mode AD, plus the value when `f` is given
-template <int MODEL>
-DYN_HD void ddyn_jac_column(const double *x, const double *u, int dir, double *col, double *f) {
-    constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
-    Dual X[NX], U[NU], Xp[NX];
-    for (int i = 0; i < NX; i++) X[i] = Dual(x[i], i == dir ? 1.0 : 0.0);
-    for (int i = 0; i < NU; i++) U[i] = Dual(u[i], NX + i == dir ? 1.0 : 0.0);
-    ddyn<MODEL, Dual>(X, U, Xp);
-    for (int i = 0; i < NX; i++) { col[i] = Xp[i].d; if (f) f[i] = Xp[i].v; }
-}
-
-// The same Jacobian column in two steps that a GPU thread can hold in registers (the one-step version above carries X, k, t, acc as dual numbers:
-// 288 registers for the rocket, 189 of them spilled): (1) ddyn_stages: the plain RK4 step, keeping the three intermediate stage points;
-// (2) ddyn_tangent: the tangent of the step along one direction, the stage points' values read back instead of carried.
+// One column of [A B] = d ddyn / d (x,u)_dir by forward-mode AD, in two steps that a GPU thread can hold in registers (pushing dual numbers
+// through the whole RK4 step carries X, k, t, acc as duals: 288 registers for the rocket, 189 of them spilled in round 1's kernel):
+// (1) ddyn_stages: the plain RK4 step, keeping the three intermediate stage points; (2) ddyn_tangent: the tangent of the step along one
+// direction, the stage points' values read back instead of carried.
 template <int MODEL>
 DYN_HD void ddyn_stages(const double *x, const double *u, double *stage /* 3*NX: x + h/2 k1, x + h/2 k2, x + h k3 */, double *xp) {
     constexpr int NX = Dims<MODEL>::NX;

@@ -383,46 +383,19 @@ __global__ void k_join_y(int B, int mb, int nx, const double *dual, const double
 // ---- kernel dispatch ---------------------------------------------------------------------------------------
 template <int NX, int NU>
 static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter, bool mx) {
-    // the fp64 kernels' LDS also holds two n-vectors of the phase logic between the sweeps (phase_update, fused look)
+    // the LDS of a QP wave also holds two n-vectors of the phase logic between the sweeps (phase_update, fused look)
     const size_t lds = std::max(mx ? QpLdsMx<NX, NU>::BYTES : sizeof(double) * (size_t)qp_lds_doubles<NX, NU>(h->d.N), sizeof(double) * (size_t)(2 * h->n + 8));
     const dim3 grid(h->B), blk(64);
     // every instance needs 1 (start) + 2 per interior-point iteration + (1 + n_refine) per polish round ticks, after at most warm_rounds + as_rounds
     // active-set rounds of the attempts that precede the interior point
     const int max_ticks = 1 + 2 * max_iter + 3 + 2 * 10 + 8 + 2 + 16 + 2 * (a.warm_rounds + a.as_rounds + 2);
-    static const bool persistent = getenv("SLSQP_PERSISTENT") ? atoi(getenv("SLSQP_PERSISTENT")) != 0 : true;
-    if (persistent) {
-        // one launch per QP solve: every wave runs its instance to completion (k_qp_solve)
-        const bool timed = h->time_kernels && h->n_kev + 2 <= (int)h->kev.size();
-        if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
-        if (mx) hipLaunchKernelGGL((k_qp_solve<NX, NU, true>), grid, blk, lds, h->st, a, max_ticks);
-        else hipLaunchKernelGGL((k_qp_solve<NX, NU, false>), grid, blk, lds, h->st, a, max_ticks);
-        if (timed) { hipEventRecord(h->kev[h->n_kev + 1], h->st); h->n_kev += 2; }
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
-    HIPCHK(hipMemsetAsync(a.n_active, 0, sizeof(int), h->st));
-    hipLaunchKernelGGL((k_phase<NX, NU>), grid, blk, 0, h->st, a, 1);
-    // tick kernels (SLSQP_PERSISTENT=0): poll the number of unfinished instances every few ticks instead of
-    // running the worst case
-    static const int first_burst = getenv("SLSQP_BURST0") ? atoi(getenv("SLSQP_BURST0")) : 12, tail_burst = getenv("SLSQP_BURST") ? atoi(getenv("SLSQP_BURST")) : 3;
-    int tick = 0, active = 1;
-    while (tick < max_ticks && active > 0) {
-        const int burst = tick < first_burst ? first_burst : tail_burst;
-        for (int i = 0; i < burst; i++, tick++) {
-            const bool timed = h->time_kernels && h->n_kev + 2 <= (int)h->kev.size();
-            if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
-            if (mx) hipLaunchKernelGGL((k_ne_fwd_mx<NX, NU>), grid, blk, lds, h->st, a);
-            else hipLaunchKernelGGL((k_ne_fwd<NX, NU>), grid, blk, lds, h->st, a);
-            if (timed) { hipEventRecord(h->kev[h->n_kev + 1], h->st); h->n_kev += 2; }
-            if (mx) hipLaunchKernelGGL((k_ne_bwd_phase_mx<NX, NU>), grid, blk, lds, h->st, a);
-            else hipLaunchKernelGGL((k_ne_bwd_phase<NX, NU>), grid, blk, lds, h->st, a);
-        }
-        HIPCHK(hipMemcpyAsync(&active, a.n_active, sizeof(int), hipMemcpyDeviceToHost, h->st));
-        HIPCHK(hipStreamSynchronize(h->st));
-    }
+    // one launch per QP solve: every wave runs its instance to completion (k_qp_solve)
+    const bool timed = h->time_kernels && h->n_kev + 2 <= (int)h->kev.size();
+    if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
+    if (mx) hipLaunchKernelGGL((k_qp_solve<NX, NU, true>), grid, blk, lds, h->st, a, max_ticks);
+    else hipLaunchKernelGGL((k_qp_solve<NX, NU, false>), grid, blk, lds, h->st, a, max_ticks);
+    if (timed) { hipEventRecord(h->kev[h->n_kev + 1], h->st); h->n_kev += 2; }
     HIPCHK(hipGetLastError());
-    for (int i = 0; i + 1 < h->n_kev; i += 2) { float ms = 0; hipEventElapsedTime(&ms, h->kev[i], h->kev[i + 1]); h->t_fwd += ms; h->n_fwd++; }
-    h->n_kev = 0;
     return 0;
 }
 
@@ -450,7 +423,7 @@ static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int w
     a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;
     a.cst = costs_of(h); a.Linv = h->Linv; a.ws = h->ws; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
     a.status = h->status; a.iters = h->iters; a.max_iter = o->qp_max_iter; a.eps = o->qp_eps;
-    a.state = h->qpstate; a.n_active = h->counter + 1; a.warm = warm; a.warm_rounds = o->warm_rounds;
+    a.state = h->qpstate; a.warm = warm; a.warm_rounds = o->warm_rounds;
     a.init_s = getenv("SLSQP_INIT_S") ? atof(getenv("SLSQP_INIT_S")) : 1.0; a.init_lam = getenv("SLSQP_INIT_LAM") ? atof(getenv("SLSQP_INIT_LAM")) : 0.0;
     const bool mx = o->precision == 1;
     h->time_kernels = o->time_kernels != 0;
@@ -709,20 +682,16 @@ static int linearize_impl(slsqp_handle *h, const double *X, const double *U, int
         dX = tmp; dU = tmp + nX;
     }
     LinArgs a{h->B, d.N, dX, dU, h->g_raw, h->gf_raw, costs_of(h), h->A, h->Bm, h->c, h->g, h->gN, h->q, run, h->lin_stage};
-    static const bool two_step = getenv("SLSQP_LIN_ONE_STEP") ? atoi(getenv("SLSQP_LIN_ONE_STEP")) == 0 : true;
     const int grid = 2048, blk = 128;
     const int gval = (int)((B * d.N + blk - 1) / blk);
     if (h->model_id == 0) {
-        if (two_step) { hipLaunchKernelGGL((k_lin_val<0>), dim3(gval), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_tan<0>), dim3(grid), dim3(blk), 0, h->st, a); }
-        else hipLaunchKernelGGL((k_lin_jac<0>), dim3(grid), dim3(blk), 0, h->st, a);
+        hipLaunchKernelGGL((k_lin_val<0>), dim3(gval), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_tan<0>), dim3(grid), dim3(blk), 0, h->st, a);
         hipLaunchKernelGGL((k_lin_vec<4, 1>), dim3(grid), dim3(256), 0, h->st, a);
     } else if (h->model_id == 1) {
-        if (two_step) { hipLaunchKernelGGL((k_lin_val<1>), dim3(gval), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_tan<1>), dim3(grid), dim3(blk), 0, h->st, a); }
-        else hipLaunchKernelGGL((k_lin_jac<1>), dim3(grid), dim3(blk), 0, h->st, a);
+        hipLaunchKernelGGL((k_lin_val<1>), dim3(gval), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_tan<1>), dim3(grid), dim3(blk), 0, h->st, a);
         hipLaunchKernelGGL((k_lin_vec<13, 4>), dim3(grid), dim3(256), 0, h->st, a);
     } else {
-        if (two_step) { hipLaunchKernelGGL((k_lin_val<2>), dim3(gval), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_tan<2>), dim3(grid), dim3(blk), 0, h->st, a); }
-        else hipLaunchKernelGGL((k_lin_jac<2>), dim3(grid), dim3(blk), 0, h->st, a);
+        hipLaunchKernelGGL((k_lin_val<2>), dim3(gval), dim3(blk), 0, h->st, a); hipLaunchKernelGGL((k_lin_tan<2>), dim3(grid), dim3(blk), 0, h->st, a);
         hipLaunchKernelGGL((k_lin_vec<17, 4>), dim3(grid), dim3(256), 0, h->st, a);
     }
     BoundsArgs ba{h->B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->ubg, h->lbg, 1e-10, run};

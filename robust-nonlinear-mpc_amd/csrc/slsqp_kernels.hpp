@@ -23,9 +23,6 @@ namespace slsqp {
 constexpr double BIGB = 1e19;   // |bound| above this is "infinite" (the reference maps +-inf to +-1e20, qp_jit.py:382)
 constexpr double EPS_PIN = 1e-10;
 constexpr int ST_INIT = -1;
-#ifndef QP_WAVES_PER_SIMD
-#define QP_WAVES_PER_SIMD 2
-#endif
 
 // NE_MFMA (default 1): the factor sweep's products T = M1 Dinv and D_k = M1 A' + B diag(pi) B' - T M1' + diag run on the fp64 matrix core
 // for NX >= 13 (wla::gemm_mfma / build_Y_mfma); 0 = vector-ALU versions.
@@ -63,7 +60,6 @@ struct QpArgs {
     double *Linv;             // scratch (B,N,NX,NX)
     double *ws;               // scratch (B, qp_ws_doubles(n,N,NX)): the IPM's n-vectors
     double *state;            // scratch (B,36): QpState
-    int *n_active;            // number of instances still iterating
     double *primal;           // (B,n)
     double *dual;             // (B,mb)
     double *cost;             // (B)
@@ -121,13 +117,8 @@ struct NeG {   // global-memory operands of the sweeps (this instance)
 //   optional (re)factorisation, block LDL':  D_k = Y_kk - O_k D_{k-1}^-1 O_k',  O_k = Y_{k,k-1} = -A_k diag(pi_x,k)
 //   (explicit symmetric inverses Dinv_k kept, written to HBM scratch),
 //   rhs b_k = E_k v - eflag * e_k, forward elimination t_k = b_k - O_k u_{k-1},  u_k = Dinv_k t_k  (u_k stored in W).
-#ifdef NE_STAMP
-#define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc_[i] += t_ - last_; last_ = t_; } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
 template <int NX, int NU>
-__device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool factor_all, double eflag, double delta, int lane, long long *dbg = nullptr,
+__device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool factor_all, double eflag, double delta, int lane,
                                           double *bmax_out = nullptr, int k0 = 0, int ks = 0) {
     // k0 > 0 (active-set rounds): the stages before k0 keep the factorisation of the previous round -- their D_k depend on Pi of the stages
     // <= k + 1 only, and no entry of Pi changed there -- so their inverses are read back from the scratch like in a solve-only sweep.
@@ -135,9 +126,6 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
     // set changed (v = -pi q on free elements, the bound on fixed ones), i.e. from stage k0 on, so u_0 .. u_{ks-1} of the previous sweep (kept in
     // UF) still hold and only u_{ks-1} and Dinv_{ks-1} are read back.
     double bmax = 0.0;
-#ifdef NE_STAMP
-    long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
-#endif
     using Ld = QpLds<NX, NU>;
     constexpr int NZ = NX + NU, SR = NX + 2 * NZ, MM = NX * NX;
     double *sA = sm + Ld::oA, *sL1 = sm + Ld::oL1, *sB = sm + Ld::oB, *sPiS = sm + Ld::oPiS, *sVS = sm + Ld::oVS;
@@ -181,7 +169,6 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
         if (lane < NZ + NX) { sPiS[lane] = rPi; sVS[lane] = rV; }
         const double ek = rE;
         wla::wsync();
-        STAMP(0);
         if (k + 1 < g.N) prefetch(k + 1);
         if (factor) {
             // M1 = A diag(pi_x,k) (into Lcur's buffer, dead until the inverse is written); the MFMA path scales its operands on the fly
@@ -190,26 +177,21 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
                 for (int o = lane; o < MM; o += 64) Lcur[o] = (k > 0) ? sA[o] * sPiS[o % NX] : 0.0;
                 wla::wsync();
             }
-            STAMP(1);
             if (k > 0) {   // T = M1 Dinv_{k-1}   (Dinv symmetric, so the NT product is the NN one)
                 if constexpr (Ld::MFMA) wla::gemm_mfma<NX, NX, NX, false, false, false, true>(sA, NX, Lprev, NX, Lprev, NX, lane, nullptr, 0, sPiS);   // in place: T replaces Dinv_{k-1}
                 else wla::gemm_nt_blk<NX, NX, NX, 3, 2>(Lcur, NX, Lprev, NX, sL1, NX, 1.0, lane);
                 wla::wsync();
             }
-            STAMP(2);
             // lower(D_k) = M1 A' + B diag(pi_u) B' + diag(pi_x,k+1) + delta - T M1'      (block LDL': D_k = Y_kk - O D_{k-1}^-1 O')
             // D_k is built where Dinv_{k-1} was (dead once T is formed: u_{k-1} is kept in sWp), inverted from there into M1's buffer
             double *sY = Lprev;
             if constexpr (Ld::MFMA) wla::build_Y_mfma<NX, NU>(sA, sPiS, sB, sPiS + NX, Lprev, k > 0, sPiS + NZ, delta, sY, lane);   // in place over T
             else wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
             wla::wsync();
-            STAMP(3);
             fail |= wla::spd_inv_gj<NX>(sY, NX, Lcur, NX, (double *)nullptr, lane);
-            STAMP(4);
             double *Lg = g.Linv + (size_t)k * MM;
 #pragma unroll
             for (int o = lane; o < MM; o += 64) Lg[o] = Lcur[o];
-            STAMP(5);
         }
         // rhs b = A v_x + B v_u - v_x,k+1 - eflag e_k  (+ A (pi_x,k .* Linv_{k-1}' w_{k-1}))
         // t_k = A (v_x + pi_x,k .* u_{k-1}) + B v_u - v_x,k+1 - eflag e_k   (u_{k-1} = Dinv_{k-1} t_{k-1} kept in sWp; the second term is -O_k u_{k-1})
@@ -225,21 +207,14 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
         if (lane < NX) { sWp[lane] = w; g.UF[k * NX + lane] = w; }
         double *t = Lcur; Lcur = Lprev; Lprev = t;
         wla::wsync();
-        STAMP(6);
     }
-#ifdef NE_STAMP
-    if (dbg && lane == 0) for (int i = 0; i < 8; i++) dbg[i] = acc_[i];
-#endif
     if (bmax_out) *bmax_out = wla::wave_max(bmax);
     return fail;
 }
 
 // Backward sweep: nu_k = u_k - Dinv_k O_{k+1}' nu_{k+1} (overwrites W) and G = E' nu.
 template <int NX, int NU>
-__device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int lane, long long *dbg = nullptr) {
-#ifdef NE_STAMP
-    long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
-#endif
+__device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int lane) {
     using Ld = QpLds<NX, NU>;
     constexpr int NZ = NX + NU, MM = NX * NX;
     double *sA = sm + Ld::oA, *sLa = sm + Ld::oQ, *sB = sm + Ld::oB, *sPiS = sm + Ld::oPiS, *sWp = sm + Ld::oWp;
@@ -267,15 +242,12 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
         for (int q = 0; q < RB; q++) { const int o = q * 64 + lane; if (o < NX * NU) sB[o] = r.B[q]; }
         if (lane < NX) { sPiS[lane] = r.Pi; sWp[lane] = r.W; }
         wla::wsync();
-        STAMP(0);
         if (k >= 2) load(k - 2, r);
-        STAMP(1);
         if (lane < NX) sT1[lane] = sPiS[lane] * sT3[lane];
         wla::wsync();
         // nu_k = u_k - Dinv_k O_{k+1}' nu_{k+1} = u_k + Dinv_k (pi_x,k+1 .* A_{k+1}' nu_{k+1})
         const double nu = sWp[lane < NX ? lane : 0] + wla::matvec_split3<NX, NX, false>(sLa, NX, sT1, lane);
         wla::wsync();
-        STAMP(2);
         if (lane < NX) {
             g.W[k * NX + lane] = nu;
             g.G[(k + 1) * NZ + lane] = sT3[lane] - nu;
@@ -288,7 +260,6 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
         if (lane < NX) sT3[lane] = ga;
         if (lane < NU) g.G[k * NZ + NX + lane] = gb;
         wla::wsync();
-        STAMP(3);
     };
     load(g.N - 1, r0);
     if (g.N >= 2) load(g.N - 2, r1);
@@ -297,9 +268,6 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
         if (k >= 1) stage(k - 1, r1);
     }
     if (lane < NX) g.G[lane] = sT3[lane];
-#ifdef NE_STAMP
-    if (dbg && lane == 0) for (int i = 0; i < 4; i++) dbg[i] = acc_[i];
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -482,7 +450,8 @@ __device__ __forceinline__ Elem elem_of(int e, int n, int N, const double *ub, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// QP solver = phase machine over three kernels per "tick" (k_ne_fwd, k_ne_bwd, k_phase), state per instance in HBM.
+// QP solver = phase machine: per "tick" a forward sweep, a backward sweep and the phase logic below (k_qp_solve loops over them), state per
+// instance in HBM.
 // Algorithm (per instance):
 //   1. equality-constrained optimum (bounds ignored) as starting point,
 //   2. Mehrotra predictor-corrector interior point; every Newton system is reduced to the block-tridiagonal
@@ -534,28 +503,6 @@ __device__ __forceinline__ FwdPlan fwd_plan(const QpState *st, int phase, int N)
     p.k0 = (phase == P_POL0) ? (int)st->kmin : 0;
     p.ks = (phase == P_POL0 && st->uf_valid != 0.0 && p.k0 < N) ? p.k0 : 0;   // (kmin = N: first tick of a QP that inherits its factorisation -- its right-hand side is new)
     return p;
-}
-
-template <int NX, int NU>
-__global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void k_ne_fwd(QpArgs a) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B || (a.run && !a.run[b])) return;
-    QpState *st = (QpState *)a.state + b;
-    const int phase = (int)st->phase;
-    if (phase == P_DONE) return;
-    extern __shared__ double sm[];
-    const FwdPlan fp = fwd_plan(st, phase, a.N);
-    const bool factor = fp.factor;
-    double bmax = 0.0;
-    const int f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane,
-#ifdef NE_STAMP_BWD
-                                     nullptr, &bmax, fp.k0, fp.ks);
-#else
-                                     (long long *)(a.kkt + (size_t)b * 8), &bmax, fp.k0, fp.ks);
-#endif
-    // in the refinement solves the right-hand side is E zn - e (+ a vanishing term): the dynamics residual of the polished point
-    if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
-    if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { atomicAdd(a.inst_launches + 1, 1ULL); atomicAdd(a.inst_launches + 2, (unsigned long long)(a.N - fp.k0)); st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
 }
 
 // first = 1: set up the instance (x0-pin check, starting rhs); else consume the solve of the current phase.
@@ -640,7 +587,6 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.uf_valid = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
-            if (status == ST_INIT) atomicAdd(a.n_active, 1);
         }
         return;
     }
@@ -1121,52 +1067,17 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             if (ok) a.cost[b] = csum;
             a.status[b] = status;
             a.iters[b] = it;
-#ifndef NE_STAMP
             double *kk = a.kkt + (size_t)b * 8;
             kk[0] = s.kst; kk[1] = s.kbox; kk[2] = s.ksign; kk[3] = s.mu; kk[4] = s.pst; kk[5] = s.pbox; kk[6] = stp->fticks; kk[7] = stp->ticks;   // [6],[7]: factor sweeps / block-tridiagonal solves this instance used
-#endif
-            atomicAdd(a.n_active, -1);
         }
     }
     if (lane == 0) { s.phase = phase; s.it = it; s.status = status; s.ticks = stp->ticks; s.fticks = stp->fticks; *stp = s; }
 }
 
-template <int NX, int NU>
-__global__ __launch_bounds__(64) void k_phase(QpArgs a, int first) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B || (a.run && !a.run[b])) return;
-    phase_update<NX, NU>(a, first, b, lane);
-}
-
-// backward sweep fused with the phase update that consumes it (one launch boundary and one pass of idle time less per tick)
-template <int NX, int NU>
-__global__ __launch_bounds__(64) void k_ne_bwd_phase(QpArgs a) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B || (a.run && !a.run[b])) return;
-    const QpState *st = (const QpState *)a.state + b;
-    if ((int)st->phase == P_DONE) return;
-    extern __shared__ double sm[];
-#ifdef NE_STAMP
-    long long *dbg = (long long *)(a.kkt + (size_t)b * 8);
-    const long long t0_ = __builtin_readcyclecounter();
-    ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane, (int)st->phase == P_INIT ? dbg : nullptr);
-    wla::wsync_mem();
-    const long long t1_ = __builtin_readcyclecounter();
-    const bool rec = (int)st->phase == P_INIT;
-    phase_update<NX, NU>(a, 0, b, lane, sm);
-    wla::wsync_mem();
-    if (rec && lane == 0) { dbg[4] = t1_ - t0_; dbg[5] = __builtin_readcyclecounter() - t1_; }
-#else
-    ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
-    wla::wsync_mem();
-    phase_update<NX, NU>(a, 0, b, lane, sm);
-#endif
-}
-
 // The whole QP solve of one instance in one launch: the wave loops over its ticks (forward sweep, backward sweep, phase logic) until its
 // instance is done, so instances advance independently -- no launch per tick, no host poll, no batch-wide barrier between ticks; the
-// hardware's workgroup dispatcher fills the slots that finished instances free.  Same device functions, same arithmetic, same results as the
-// tick kernels (k_phase / k_ne_fwd / k_ne_bwd_phase), which remain for the mixed-precision path.
+// hardware's workgroup dispatcher fills the slots that finished instances free.  (Round 1 launched one kernel per part and tick and polled a
+// counter of unfinished instances from the host.)
 #ifndef QP_PERSIST_WAVES_PER_SIMD
 #define QP_PERSIST_WAVES_PER_SIMD 3
 #endif
@@ -1199,7 +1110,7 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
         double bmax = 0.0;
         int f;
         if constexpr (MX) f = ne_forward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, &bmax, fp.k0);
-        else f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, nullptr, &bmax, fp.k0, fp.ks);
+        else f = ne_forward<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, &bmax, fp.k0, fp.ks);
         if (lane == 0) {
             if (phase == P_POL1 || phase == P_POL2) st->pbox = bmax;
             st->ticks += 1.0;
@@ -1226,36 +1137,6 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
     if (lane == 0) { double *kk = a.kkt + (size_t)b * 8; kk[2] = (double)c_fwdf; kk[3] = (double)(double)n_fstages; kk[4] = (double)c_fwd; kk[5] = (double)c_bwd; kk[6] = (double)c_ph; kk[7] = (double)(__builtin_readcyclecounter() - c_t0); }
 #endif
     if (lane == 0) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); atomicAdd(a.inst_launches + 2, n_fstages); atomicAdd(a.inst_launches + 3, 1ULL); }
-}
-
-#ifndef QP_MX_WAVES_PER_SIMD
-#define QP_MX_WAVES_PER_SIMD 3
-#endif
-template <int NX, int NU>
-__global__ __launch_bounds__(64, QP_MX_WAVES_PER_SIMD) void k_ne_fwd_mx(QpArgs a) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B || (a.run && !a.run[b])) return;
-    QpState *st = (QpState *)a.state + b;
-    const int phase = (int)st->phase;
-    if (phase == P_DONE) return;
-    extern __shared__ double sm[];
-    const FwdPlan fp = fwd_plan(st, phase, a.N);
-    const bool factor = fp.factor;
-    double bmax = 0.0;
-    const int f = ne_forward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), fp.factor, fp.eflag, fp.delta, lane, &bmax, fp.k0);
-    if (lane == 0 && (phase == P_POL1 || phase == P_POL2)) st->pbox = bmax;
-    if (lane == 0) { st->ticks += 1.0; atomicAdd(a.inst_launches, 1ULL); if (factor) { atomicAdd(a.inst_launches + 1, 1ULL); atomicAdd(a.inst_launches + 2, (unsigned long long)(a.N - fp.k0)); st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; } }
-}
-template <int NX, int NU>
-__global__ __launch_bounds__(64) void k_ne_bwd_phase_mx(QpArgs a) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B || (a.run && !a.run[b])) return;
-    const QpState *st = (const QpState *)a.state + b;
-    if ((int)st->phase == P_DONE) return;
-    extern __shared__ double sm[];
-    ne_backward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
-    wla::wsync_mem();
-    phase_update<NX, NU>(a, 0, b, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2112,21 +1993,6 @@ __global__ __launch_bounds__(128) void k_lin_tan(LinArgs a) {
         dyn::ddyn_tangent<MODEL>(x, u, a.stage + bk * 3 * NX, dir, col);
         if (dir < NX) { double *A = a.A + bk * NX * NX; for (int i = 0; i < NX; i++) A[i * NX + dir] = col[i]; }
         else { double *Bm = a.Bm + bk * NX * NU; for (int i = 0; i < NX; i++) Bm[i * NU + (dir - NX)] = col[i]; }
-    }
-}
-template <int MODEL>
-__global__ __launch_bounds__(128) void k_lin_jac(LinArgs a) {
-    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU, NZ = NX + NU;
-    const size_t tot = (size_t)a.B * a.N * NZ;
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
-        const int dir = t % NZ, k = (t / NZ) % a.N, b = t / ((size_t)NZ * a.N);
-        if (a.run && !a.run[b]) continue;
-        const double *x = a.X + ((size_t)b * (a.N + 1) + k) * NX, *u = a.U + ((size_t)b * a.N + k) * NU;
-        double col[NX], f[NX];
-        dyn::ddyn_jac_column<MODEL>(x, u, dir, col, dir == 0 ? f : nullptr);
-        if (dir < NX) { double *A = a.A + ((size_t)b * a.N + k) * NX * NX; for (int i = 0; i < NX; i++) A[i * NX + dir] = col[i]; }
-        else { double *Bm = a.Bm + ((size_t)b * a.N + k) * NX * NU; for (int i = 0; i < NX; i++) Bm[i * NU + (dir - NX)] = col[i]; }
-        if (dir == 0) { double *c = a.c + ((size_t)b * a.N + k) * NX; for (int i = 0; i < NX; i++) c[i] = f[i] - x[NX + i]; }
     }
 }
 template <int NX, int NU>

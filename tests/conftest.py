@@ -21,3 +21,15 @@ def golden_dir():
 
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name)))
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _limit_blas_threads():
+    """numpy / scipy ship an OpenBLAS built for at most 64 threads; on hosts with more cores (the GPU boxes) its threaded LU has crashed the test
+    process (segmentation fault inside scipy.linalg.lu_factor, tests/ref_ipm.py).  The test infrastructure does not need more than a few threads."""
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=8):
+            yield
+    except ImportError:
+        yield

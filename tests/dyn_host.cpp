@@ -4,9 +4,10 @@
 using namespace dyn;
 template <int M> static void jac(const double *x, const double *u, double *A, double *B, double *f) {
     constexpr int NX = Dims<M>::NX, NU = Dims<M>::NU;
-    double col[NX];
+    double col[NX], st[3 * NX];
+    ddyn_stages<M>(x, u, st, f);                 // the product's linearisation path: k_lin_val ...
     for (int d = 0; d < NX + NU; d++) {
-        ddyn_jac_column<M>(x, u, d, col, d == 0 ? f : nullptr);
+        ddyn_tangent<M>(x, u, st, d, col);       // ... and k_lin_tan
         for (int i = 0; i < NX; i++) { if (d < NX) A[i * NX + d] = col[i]; else B[i * NU + (d - NX)] = col[i]; }
     }
 }

@@ -199,10 +199,18 @@ def qp_statistics(stats):
     S = np.stack(stats)                                   # (steps, B, 2, 8)
     for slot, name in ((0, "qp1"), (1, "qp2")):
         q = S[:, :, slot, :]
+        st_all = q[..., 6]
+        # status -1: the instance was not part of this solve (its step had failed before); 2: the measured state contradicts its own stage-0 box,
+        # flagged before any work.  The figures below are over the solves that ran.
+        ran = (st_all != -1) & (st_all != 2)
+        head = {"not_run_frac": float((st_all == -1).mean()), "infeasible_x0_frac": float((st_all == 2).mean()), "ran_frac": float(ran.mean())}
+        nact_all = q[..., 3]
+        q = q[ran]
         its, blk, fac, nact, warm, rounds, st, fb = (q[..., i] for i in range(8))
         solved = (st == 0) | (st == 4)
         cold = its > 0
         out[name] = {
+            **head,
             "solved_frac": float(solved.mean()), "certified_frac": float((st == 0).mean()),
             "started_warm_frac": float(warm.mean()), "interior_point_frac": float(cold.mean()),
             # how the solve got to its answer: first active-set attempt (warm set, or the empty set on a cold solve) / interior point from scratch /
@@ -215,7 +223,7 @@ def qp_statistics(stats):
             "factorisations_mean": float(fac.mean()),
             "active_inequalities": {"mean": float(nact.mean()), "p50": float(np.percentile(nact, 50)), "p99": float(np.percentile(nact, 99)), "max": int(nact.max()),
                                     "histogram_per_step": {"edges": [0, 1, 6, 11, 21, 41, 10 ** 9],
-                                                           "counts": [np.histogram(nact[s], bins=[0, 1, 6, 11, 21, 41, 10 ** 9])[0].tolist() for s in range(S.shape[0])]}},
+                                                           "counts": [np.histogram(nact_all[s][ran[s]], bins=[0, 1, 6, 11, 21, 41, 10 ** 9])[0].tolist() for s in range(S.shape[0])]}},
         }
     return out
 
@@ -359,14 +367,21 @@ def main():
         extra_cfg = {}
     k_ms, k_launches, inst_sweeps, mx_retries = dev.kernel_timing()
     fact_stages, qp_solves = dev.factor_stages, dev.qp_solves
+    qp_done = float(qp_solves)      # QP solves of the timed region that actually ran (device counter), this rank
     if world > 1:
         tmax = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        tsum = torch.tensor([qp_done], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        qp_done = float(tsum.item())
     n_sl = len(dev.bounds)
     # QP solves per instance and step: closed loop = rti SCP iterations x (fast_sls_rti_steps + 1) QPs (rocket script: 1 x 2; pendulum / quadrotor: 3 x 3)
     qp_per_inst = (m.rti * (m.fast_sls_rti_steps + 1)) if args.workload == "closed_loop" else ((m.fast_sls_rti_steps if args.model == "rocket" else 1) + 1)
-    value = qp_per_inst * B * world * args.steps / dt
+    # value counts the QP solves that RAN: an MPC step whose measured state lies outside its own stage-0 box (noise pushed it over a state bound the
+    # nominal touches) is flagged infeasible before any work, as the reference's QP would be, and its two QPs are not counted
+    qp_nominal = qp_per_inst * B * world * args.steps
+    value = qp_done / dt
     headline = (args.model, B, args.workload) == ("rocket", 4096, "closed_loop")
     out = {
         "metric": ("QP solves/sec (whole node), rockETH N=20 batch=4096 closed-loop RTI MPC step" if headline
@@ -374,7 +389,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 0 else "f32 factorisation + f64 residuals (mixed)",
         "data": "synthetic",
-        "config": dict({"workload": workload, "qp_n": n_var, "qp_m": N * (m.nx + m.ni) + m.ni_f + m.nx, "slices_per_gpu": n_sl}, **extra_cfg),
+        "config": dict({"workload": workload, "qp_n": n_var, "qp_m": N * (m.nx + m.ni) + m.ni_f + m.nx, "slices_per_gpu": n_sl,
+                        "qp_solves_counted": qp_done, "qp_solves_nominal": qp_nominal, "qp_solves_executed_frac": qp_done / qp_nominal}, **extra_cfg),
     }
     if rank == 0:
         st = dev.get("status", (), np.int32)

@@ -49,6 +49,7 @@ struct slsqp_handle {
     double *eta, *eta_f, *beta, *beta_f, *backoff, *backoff_f, *backoff_x, *backoff_u, *K;
     int *status, *iters, *itnum, *has_prev, *conv, *alive, *mask, *success, *infeas, *counter;
     int *scp_active, *scp_success, *scp_iters, *pending_reset, *scp_upd; double *scp_dmax;
+    int horizon_shifted = 0;
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
     int *retry; int mx_retry, mx_retry_total;
     double *Kc, *Aclc;          // (B,N,nu,nx), (B,N,nx,nx): K_k and A_k + B_k K_k of the shared Riccati recursion (k_sweep_ric1 -> k_sweep_prop)
@@ -65,7 +66,7 @@ struct slsqp_handle {
     bool beta_inited;           // beta / beta_f have been filled with eps once (k_init_backoff); later solves only repair swept instances (k_fix_beta)
     bool general_G;             // G, Gf are not [I;-I]: only the sweep-level boundary (slsqp_sweep) is available
     double *Gd, *Gfd;           // device copies of G (ni, nx+nu) and Gf (ni_f, nx) when general_G
-    hipEvent_t ev[8];
+    hipEvent_t ev[10];
     std::vector<hipEvent_t> kev;   // event pairs around every k_ne_fwd launch of the last QP solve (only with opts.time_kernels)
     int n_kev; bool time_kernels;
     double t_total, t_qp, t_sweep, t_fwd; int n_fwd; double fwd_inst;   // fwd_inst: sum over launches of instances that did work
@@ -414,11 +415,13 @@ __global__ void k_mark_retry(int B, const int *run, const int *status, int *retr
     if (r) atomicAdd(count, 1);
 }
 
-static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr, int stat_slot = 0, int snap_take = 0, int snap_use = 0) {
+static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr, int stat_slot = 0, int snap_take = 0, int snap_use = 0,
+                     int warm_shift = 0) {
     QpArgs a;
     a.qpstat = h->qpstat; a.stat_slot = stat_slot;
     static const double snap_mu = getenv("SLSQP_SNAP_MU") ? atof(getenv("SLSQP_SNAP_MU")) : 1e-3;
     a.snap_take = snap_take; a.snap_use = snap_use && o->ipm_restart; a.snap_mu = snap_mu; a.call_id = h->call_id; a.as_first = o->as_first; a.as_rounds = o->as_rounds; a.as_max_viol = o->as_max_viol;
+    { static const int ws = getenv("SLSQP_WARM_SHIFT") ? atoi(getenv("SLSQP_WARM_SHIFT")) : 1; a.warm_shift = ws ? warm_shift : 0; }
     a.prox = prox; a.prox_stride = 12; a.inst_launches = h->inst_launches;
     a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;
     a.cst = costs_of(h); a.Linv = h->Linv; a.ws = h->ws; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
@@ -520,7 +523,8 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     const bool rti = o.rti_steps > 0;
     const int steps = rti ? o.rti_steps : o.max_sls_iter;
     h->call_id += 1.0;
-    std::vector<float> tq, ts;
+    // the caller moved the horizon one stage on since the last solve (slsqp_cl_step's reset_warm_start): the first QP's warm set moves with it
+    const int wshift = h->horizon_shifted; h->horizon_shifted = 0;
     HIPCHK(hipEventRecord(h->ev[0], h->st));
     if (active) hipLaunchKernelGGL(k_copy_int, dim3(gb), dim3(256), 0, h->st, active, h->alive, B);
     else hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->alive, 1, B);
@@ -542,9 +546,10 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         h->beta_inited = true;
     }
     double acc_qp = 0, acc_sw = 0;
+    bool deferred = false;
     for (int i = 0; i < steps; i++) {
         HIPCHK(hipEventRecord(h->ev[1], h->st));
-        if (launch_qp(h, h->alive, &o, (i > 0 || o.warm_start) ? 1 : 0, nullptr, 0, 1, i > 0 ? 1 : 0)) return -1;
+        if (launch_qp(h, h->alive, &o, (i > 0 || o.warm_start) ? 1 : 0, nullptr, 0, 1, i > 0 ? 1 : 0, i == 0 ? wshift : 0)) return -1;
         HIPCHK(hipEventRecord(h->ev[2], h->st));
         hipLaunchKernelGGL(k_post_qp, dim3(gb), dim3(256), 0, h->st, B, h->status, h->alive, h->infeas);
         EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff, h->stale, (i == 0 && sweep_shared_allowed()) ? 1 : 0};
@@ -559,6 +564,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         HIPCHK(hipEventRecord(h->ev[4], h->st));
         TightenArgs ta{B, d.N, d.nx, d.nu, d.ni, d.ni_f, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1, h->ct_part, h->cost_tube};
         hipLaunchKernelGGL(k_tighten, dim3(B), dim3(128), 0, h->st, ta);
+        if (rti && steps == 1) { deferred = true; continue; }   // the script setting of the rocket: nothing to decide on the host, the stream runs on into the final QP
         int nmask = 0;
         HIPCHK(hipMemcpyAsync(&nmask, h->counter, sizeof(int), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
@@ -567,14 +573,15 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         if (!rti && nmask == 0) break;   // every instance converged or failed
     }
     // final QP: RTI always (fast_SLS_jit.py:293); converge mode only for instances that hit MAX_ITER (:311)
-    HIPCHK(hipEventRecord(h->ev[1], h->st));
+    HIPCHK(hipEventRecord(h->ev[8], h->st));
     if (launch_qp(h, h->alive, &o, 1, nullptr, 1, 1, 1)) return -1;
-    HIPCHK(hipEventRecord(h->ev[2], h->st));
+    HIPCHK(hipEventRecord(h->ev[9], h->st));
     hipLaunchKernelGGL(k_finish, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->alive, h->infeas, h->success, active, h->pending_reset);
     HIPCHK(hipEventRecord(h->ev[5], h->st));
     HIPCHK(hipStreamSynchronize(h->st));
     harvest_kernel_events(h);
-    acc_qp += ev_ms(h->ev[1], h->ev[2]);
+    if (deferred) { acc_qp += ev_ms(h->ev[1], h->ev[2]); acc_sw += ev_ms(h->ev[3], h->ev[4]); }
+    acc_qp += ev_ms(h->ev[8], h->ev[9]);
     h->t_total = ev_ms(h->ev[0], h->ev[5]); h->t_qp = acc_qp; h->t_sweep = acc_sw;
     return 0;
 }
@@ -834,6 +841,7 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
         else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_shift_plant<1>), dim3(gb), dim3(64), 0, h->st, a, 1, 0);
         else hipLaunchKernelGGL((k_cl_shift_plant<2>), dim3(gb), dim3(64), 0, h->st, a, 1, 0);
         if (slsqp_reset(h)) return -1;
+        h->horizon_shifted = 1;
     }
     double tq = 0, ts = 0, tt = 0;
     slsqp_opts o;
@@ -861,10 +869,11 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
         if (h->model_id == 0) hipLaunchKernelGGL((k_cl_infeas<0>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
         else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_infeas<1>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
         else hipLaunchKernelGGL((k_cl_infeas<2>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
+        if (ii + 1 == max_it) break;
         int nact = 0;
         HIPCHK(hipMemcpyAsync(&nact, h->counter + 2, sizeof(int), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
-        if (nact == 0 || ii + 1 == max_it) break;
+        if (nact == 0) break;
         HIPCHK(hipEventRecord(h->ev[6], h->st));
         if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, h->scp_active)) return -1;   // update_jacobian for the next iteration (:138)
         HIPCHK(hipEventRecord(h->ev[7], h->st));

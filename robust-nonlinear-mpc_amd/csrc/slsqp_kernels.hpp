@@ -74,7 +74,8 @@ struct QpArgs {
     int warm;                 // 1: try an active-set polish from the previous solution of each instance first
     const double *prox;       // per-instance proximal weight added to the diagonal cost (element b * prox_stride), or NULL
     int prox_stride;
-    unsigned long long *inst_launches;   // [0] += 1 per instance forward sweep, [1] += 1 per factorising one, [2] += stages it factorised, [3] += QP solves
+    unsigned long long *inst_launches;   // [0] += 1 per instance forward sweep, [1] += 1 per factorising one, [2] += stages it factorised, [3] += QP solves that ran at least one block solve (an instance whose x0 pin
+                                         // contradicts its own box is flagged at once and not counted)
                                          // (roofline accounting of bench.py)
     int *qpstat;              // (B,2,8) or NULL: per instance and slot [its, block solves, factorising ones, active inequality rows, started warm,
     int stat_slot;            //   active-set correction rounds, status, fell back to the interior point]; slot = 0 first QP of a fast-SLS call, 1 its last QP
@@ -84,6 +85,7 @@ struct QpArgs {
     double call_id;           // identifies the fast-SLS call (a copy is only valid within the call that took it: same A, B, q)
     int as_first;             // 1: a cold solve first tries the active-set iteration from the empty set (the equality-constrained optimum of P_INIT)
     int as_rounds;            // rounds such an attempt may take (a warm one: warm_rounds)
+    int warm_shift;           // 1: the first QP's warm set is the previous call's set moved one stage towards the start of the horizon (receding horizon)
     int as_max_viol;          // an attempt is abandoned when a solve leaves more violated bounds than this, or more than 2 x the previous round's + 8
     int n_refine;             // refinement solves per polish (1 in fp64, 3 with fp32 factorisations)
     double early_ctol;        // tolerance (relative to max(1,|q|inf)) of the look at the un-refined polish solve: its accuracy class
@@ -545,11 +547,13 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         }
         if (wla::wave_max(viol) > 1e-9) status = 2;
         // warm start: the previous solve of this instance ended with a certified active set -> polish from it first
-        const bool warm = a.warm && ((int)stp->status == 0) && ((int)stp->phase == P_DONE) && status == ST_INIT;
+        // the first QP of a call starts from the set the first QP of an earlier call ended on (the un-tightened QPs of consecutive MPC steps
+        // resemble each other more than a tightened and an un-tightened one: 2.8 against 3.9 rounds, scripts/proto/as_warm_sources.py) -- also
+        // when the solve in between did not end on a certificate (e.g. a measured state outside its own box, status 2): ACT1 is only ever
+        // written with a certified set
+        const bool from_act1 = a.warm && status == ST_INIT && a.stat_slot == 0 && a.snap_use == 0 && stp->act1_ok != 0.0;
+        const bool warm = a.warm && status == ST_INIT && (from_act1 || (((int)stp->status == 0) && ((int)stp->phase == P_DONE)));
         const double *prev = a.primal + (size_t)b * n;
-        // the first QP of a call starts from the set the first QP of the previous call ended on (the un-tightened QPs of consecutive MPC steps
-        // resemble each other more than a tightened and an un-tightened one: 2.8 against 3.9 rounds, scripts/proto/as_warm_sources.py)
-        const bool from_act1 = warm && a.stat_slot == 0 && a.snap_use == 0 && stp->act1_ok != 0.0;
         // a later QP of the same call whose previous solve was certified: same A, B, weights, and the scratch still holds the factorisation of
         // exactly the set it starts from -- its first tick needs no factorisation at all
         const bool keep_fact = warm && !from_act1 && a.snap_use != 0 && stp->fact_call == a.call_id && a.call_id != 0.0;
@@ -562,7 +566,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             mtot += (el.fu ? 1.0 : 0.0) + (el.fl ? 1.0 : 0.0);
             if (warm) {
                 const double ac_old = ACT[e];
-                double ac = from_act1 ? ACT1[e] : ac_old;
+                double ac = from_act1 ? ((a.warm_shift && e + NZ < n) ? ACT1[e + NZ] : ACT1[e]) : ac_old;
                 if ((ac > 0.0 && !el.fu) || (ac < 0.0 && !el.fl) || !el.fr) ac = 0.0;
                 if (ac != ac_old) set_changed = 1.0;
                 const double zp = (e < NX) ? a.x0val[(size_t)b * NX + e] : prev[e];
@@ -587,6 +591,11 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.uf_valid = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
+            if (status != ST_INIT && a.qpstat) {   // flagged without a solve: the statistics of this slot must not show the previous call's
+                int *qs = a.qpstat + ((size_t)b * 2 + a.stat_slot) * 8;
+                for (int i = 0; i < 8; i++) qs[i] = 0;
+                qs[6] = status;
+            }
         }
         return;
     }
@@ -1084,7 +1093,11 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
 template <int NX, int NU, bool MX = false>     // MX: the mixed-precision sweeps (ne_forward_mx / ne_backward_mx, section 2.4 of DESIGN.md), same loop and phase logic
 __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpArgs a, int max_ticks) {
     int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B || (a.run && !a.run[b])) return;
+    if (b >= a.B) return;
+    if (a.run && !a.run[b]) {       // not part of this solve: its statistics slot says so (status -1)
+        if (a.qpstat && lane < 8) a.qpstat[((size_t)b * 2 + a.stat_slot) * 8 + lane] = (lane == 6) ? -1 : 0;
+        return;
+    }
     extern __shared__ double sm[];
     phase_update<NX, NU>(a, 1, b, lane);
     wla::wsync_mem();
@@ -1136,7 +1149,7 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
 #ifdef QP_STAMP
     if (lane == 0) { double *kk = a.kkt + (size_t)b * 8; kk[2] = (double)c_fwdf; kk[3] = (double)(double)n_fstages; kk[4] = (double)c_fwd; kk[5] = (double)c_bwd; kk[6] = (double)c_ph; kk[7] = (double)(__builtin_readcyclecounter() - c_t0); }
 #endif
-    if (lane == 0) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); atomicAdd(a.inst_launches + 2, n_fstages); atomicAdd(a.inst_launches + 3, 1ULL); }
+    if (lane == 0) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); atomicAdd(a.inst_launches + 2, n_fstages); atomicAdd(a.inst_launches + 3, n_sweeps ? 1ULL : 0ULL); }
 }
 
 // ------------------------------------------------------------------------------------------------

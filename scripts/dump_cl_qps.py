@@ -28,7 +28,7 @@ for i in range(steps):
     qs = out[f"qp_stats_{i}"]
     pf = lambda k: "/".join(f"{np.mean(qs[:, k, 7] == v):.2f}" for v in range(4))
     print(f"step {i}: success {out[f'success_{i}'].mean():.3f} | QP1 its>0 {np.mean(qs[:,0,0]>0):.3f} ticks {qs[:,0,1].mean():.1f} (max {qs[:,0,1].max()}) rounds {qs[:,0,5].mean():.1f} nact {qs[:,0,3].mean():.1f} warm {qs[:,0,4].mean():.2f} path {pf(0)}"
-          f" | QP2 its>0 {np.mean(qs[:,1,0]>0):.3f} ticks {qs[:,1,1].mean():.1f} (max {qs[:,1,1].max()}) rounds {qs[:,1,5].mean():.1f} nact {qs[:,1,3].mean():.1f} path {pf(1)} | status {np.bincount(qs[:,1,6], minlength=5)}", flush=True)
+          f" | QP2 its>0 {np.mean(qs[:,1,0]>0):.3f} ticks {qs[:,1,1].mean():.1f} (max {qs[:,1,1].max()}) rounds {qs[:,1,5].mean():.1f} nact {qs[:,1,3].mean():.1f} path {pf(1)} | status(-1..4) {np.bincount(qs[:,1,6] + 1, minlength=6)}", flush=True)
 cl.close()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", "cl_qps.npz"), **out)

@@ -30,15 +30,17 @@ def sets_of(step, b):
 
 
 tot = {}
-for b in range(0, 256, 23):
+for b in range(0, 64, 7):
     prev = None
     for step in range(1, 6):
         if not d[f"success_{step}"][b] or (prev is not None and not d[f"success_{step-1}"][b]):
             prev = None
         cur = sets_of(step, b)
         if prev is not None:
-            cands1 = {"empty": np.zeros(n, dtype=int), "A2(t-1)": prev["a2"], "A1(t-1)": prev["a1"], "shift A1(t-1)": shift(prev["a1"]), "shift A2(t-1)": shift(prev["a2"])}
-            cands2 = {"A1(t)": cur["a1"], "A2(t-1)": prev["a2"], "shift A2(t-1)": shift(prev["a2"]), "empty": np.zeros(n, dtype=int)}
+            uni = lambda x, y: np.where(x != 0, x, y)
+            cands1 = {"A1(t-1)": prev["a1"], "shift A1(t-1)": shift(prev["a1"]), "A1 u shiftA1": uni(prev["a1"], shift(prev["a1"]))}
+            cands2 = {"A1(t)": cur["a1"], "shift A2(t-1)": shift(prev["a2"]), "A1(t) u shiftA2(t-1)": uni(cur["a1"], shift(prev["a2"])), "A1(t) u A2(t-1)": uni(cur["a1"], prev["a2"]),
+                      "A1(t) u (A2-A1)(t-1)": uni(cur["a1"], np.where(prev["a1"] == 0, prev["a2"], 0))}
             line = f"inst {b} step {step}:"
             for nm, a0 in cands1.items():
                 a, z, r, ok, h = polish3(cur["E"], cur["e"], cur["q"], *cur["b1"], a0, "inputs_first")

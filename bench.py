@@ -183,7 +183,8 @@ class ClosedLoopSlices:
         self.fwd_factor_sweeps = self.factor_stages = self.qp_solves = 0
         for cl in self.cl:
             ms, n = cl.f.kernel_timing()
-            tot[0] += ms; tot[1] += n; tot[2] += cl.f.fwd_instance_sweeps; tot[3] += cl.f.mx_retries
+            tot[0] += ms; tot[1] += n; tot[2] += cl.f.fwd_instance_sweeps - 0.5 * cl.f.bwd_sweeps_skipped;      # a forward-only residual check counts as half a block solve
+            tot[3] += cl.f.mx_retries
             self.fwd_factor_sweeps += cl.f.fwd_factor_sweeps; self.factor_stages += cl.f.factor_stages; self.qp_solves += cl.f.qp_solves
         return tuple(tot)
 

@@ -147,7 +147,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(h->owned, &h->u0, B * nu); rc |= dalloc(h->owned, &h->wbuf, B * nx); rc |= dalloc(h->owned, &h->u_init, (size_t)nu); h->cl_steps = 0; rc |= dalloc(h->owned, &h->cst, (size_t)(3 * nx + 2 * nu) * 2);
     rc |= dalloc(h->owned, &h->ubg, B * h->mb); rc |= dalloc(h->owned, &h->lbg, B * h->mb);
     rc |= dalloc(h->owned, &h->primal, B * h->n); rc |= dalloc(h->owned, &h->dual, B * h->mb); rc |= dalloc(h->owned, &h->cost, B); rc |= dalloc(h->owned, &h->pin_dual, B * nx);
-    rc |= dalloc(h->owned, &h->kkt, B * 8); rc |= dalloc(h->owned, &h->prev_primal, B * h->n); rc |= dalloc(h->owned, &h->Linv, B * N * nx * nx); rc |= dalloc(h->owned, &h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(h->owned, &h->qpstate, B * 36);
+    rc |= dalloc(h->owned, &h->kkt, B * 8); rc |= dalloc(h->owned, &h->prev_primal, B * h->n); rc |= dalloc(h->owned, &h->Linv, B * N * nx * nx); rc |= dalloc(h->owned, &h->ws, B * qp_ws_doubles(h->n, N, nx)); rc |= dalloc(h->owned, &h->qpstate, B * 40);
     rc |= dalloc(h->owned, &h->eta, B * N * N * ni); rc |= dalloc(h->owned, &h->eta_f, B * (N + 1) * nif); rc |= dalloc(h->owned, &h->beta, B * N * N * ni);
     rc |= dalloc(h->owned, &h->beta_f, B * (N + 1) * nif); rc |= dalloc(h->owned, &h->backoff, B * N * ni); rc |= dalloc(h->owned, &h->backoff_f, B * nif);
     rc |= dalloc(h->owned, &h->backoff_x, B * (N + 1) * nx); rc |= dalloc(h->owned, &h->backoff_u, B * N * nu); rc |= dalloc(h->owned, &h->K, B * N * (N + 1) * nu * nx);
@@ -157,7 +157,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(h->owned, &h->retry, B); h->mx_retry = 0; h->mx_retry_total = 0;
     rc |= dalloc(h->owned, &h->nom_st, B * 12); rc |= dalloc(h->owned, &h->nom_need_lin, B); rc |= dalloc(h->owned, &h->nom_status, B); rc |= dalloc(h->owned, &h->nom_iters, B);
     rc |= dalloc(h->owned, &h->mapA, (size_t)N * nx * nx); rc |= dalloc(h->owned, &h->mapB, (size_t)N * nx * nu);
-    rc |= dalloc(h->owned, &h->inst_launches, (size_t)4); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
+    rc |= dalloc(h->owned, &h->inst_launches, (size_t)8); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
     rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->Kc, B * N * nu * nx); rc |= dalloc(h->owned, &h->Aclc, B * N * nx * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->Gd, (size_t)ni * (nx + nu)); rc |= dalloc(h->owned, &h->Gfd, (size_t)nif * nx); h->general_G = false; h->beta_inited = false; rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
     h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { free_all(h->owned); hipStreamDestroy(h->st); delete h; return nullptr; }
@@ -593,13 +593,13 @@ extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms5) {
     return 0;
 }
 extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out8) {
-    unsigned long long il[4] = {0, 0, 0, 0};
+    unsigned long long il[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipSetDevice(h->dev);
     hipMemcpyAsync(il, h->inst_launches, sizeof(il), hipMemcpyDeviceToHost, h->st);
     hipMemsetAsync(h->inst_launches, 0, sizeof(il), h->st);
     hipStreamSynchronize(h->st);
     out8[0] = h->t_fwd; out8[1] = (double)h->n_fwd; out8[2] = (double)h->mx_retry_total; out8[3] = (double)il[0]; out8[4] = (double)il[1];
-    out8[5] = (double)il[2]; out8[6] = (double)il[3]; out8[7] = 0.0;
+    out8[5] = (double)il[2]; out8[6] = (double)il[3]; out8[7] = (double)il[4];
     h->t_fwd = 0; h->n_fwd = 0; h->mx_retry_total = 0;
     return 0;
 }

@@ -59,7 +59,7 @@ struct QpArgs {
     Costs cst;
     double *Linv;             // scratch (B,N,NX,NX)
     double *ws;               // scratch (B, qp_ws_doubles(n,N,NX)): the IPM's n-vectors
-    double *state;            // scratch (B,36): QpState
+    double *state;            // scratch (B,40): QpState
     double *primal;           // (B,n)
     double *dual;             // (B,mb)
     double *cost;             // (B)
@@ -74,7 +74,7 @@ struct QpArgs {
     int warm;                 // 1: try an active-set polish from the previous solution of each instance first
     const double *prox;       // per-instance proximal weight added to the diagonal cost (element b * prox_stride), or NULL
     int prox_stride;
-    unsigned long long *inst_launches;   // [0] += 1 per instance forward sweep, [1] += 1 per factorising one, [2] += stages it factorised, [3] += QP solves that ran at least one block solve (an instance whose x0 pin
+    unsigned long long *inst_launches;   // [0] += 1 per instance forward sweep, [1] += 1 per factorising one, [2] += stages it factorised, [4] += block solves whose backward sweep was skipped; [3] += QP solves that ran at least one block solve (an instance whose x0 pin
                                          // contradicts its own box is flagged at once and not counted)
                                          // (roofline accounting of bench.py)
     int *qpstat;              // (B,2,8) or NULL: per instance and slot [its, block solves, factorising ones, active inequality rows, started warm,
@@ -467,7 +467,15 @@ __device__ __forceinline__ Elem elem_of(int e, int n, int N, const double *ub, c
 // finished instances exit at once.  Splitting the former single kernel removed 340 VGPR + 382 SGPR spills.
 // ------------------------------------------------------------------------------------------------
 enum { P_INIT = 0, P_PRED = 1, P_CORR = 2, P_POL0 = 3, P_POL1 = 4, P_POL2 = 5, P_DONE = 6 };
-struct QpState {   // per instance, 36 doubles
+// equality residual (relative to max(1,|q|inf)) below which an un-refined active-set solve is accepted without the refinement solve (the certificate
+// itself asks for 1e-6; a solve that misses this tighter bound is refined as before)
+#ifndef AS_DELTA
+#define AS_DELTA 1e-13      // diagonal regularisation of the active-set rounds' factorisations
+#endif
+#ifndef RES_ONLY_TOL
+#define RES_ONLY_TOL 1e-9
+#endif
+struct QpState {   // per instance, 40 doubles
     double phase, it, status, mu, smu, qscale, mtot, pol_round, pol_fail, warm, kst, kbox, ksign, pst, pbox, psign, ticks, fticks, tight, pad;
     double snap_call, snap_mu, snap_used, pad2;   // call that took the iterate copy (0 = none), its mu, 1 = this solve restarted from it
     double mode, cold_as, nviol, path;            // mode 1: P_INIT starts the interior point (0: an active-set attempt from the empty set);
@@ -478,7 +486,11 @@ struct QpState {   // per instance, 36 doubles
                                                   // fact_call: call whose last certified solve left its factorisation (for the set in ACT) in the
                                                   // scratch; act1_ok: ACT1 holds a certified set; uf_valid: the last forward sweep solved the current attempt's
                                                   // un-refined system, so UF's leading u_k carry over to the next round (ne_forward ks)
+    double res_only, tbox, pad3, pad4;            // res_only 1: the look at the un-refined solve already found stationarity, box and multiplier signs within the
+                                                  // certificate's tolerance (tbox: its box violation); the tick that follows only has to measure the equality
+                                                  // residual -- if that is small too the un-refined solve IS the certified answer and the refinement is skipped
 };
+static_assert(sizeof(QpState) == 40 * sizeof(double), "QpState size");
 
 template <int NX, int NU>
 __device__ __forceinline__ NeG<NX, NU> make_neg(const QpArgs &a, int b) {
@@ -501,7 +513,7 @@ __device__ __forceinline__ FwdPlan fwd_plan(const QpState *st, int phase, int N)
     FwdPlan p;
     p.factor = (phase == P_INIT || phase == P_PRED || phase == P_POL0);
     p.eflag = (phase == P_INIT || phase >= P_POL0) ? 1.0 : 0.0;
-    p.delta = (phase == P_POL0 || (phase == P_INIT && st->mode == 0.0)) ? 1e-10 : 0.0;
+    p.delta = (phase == P_POL0 || (phase == P_INIT && st->mode == 0.0)) ? AS_DELTA : 0.0;
     p.k0 = (phase == P_POL0) ? (int)st->kmin : 0;
     p.ks = (phase == P_POL0 && st->uf_valid != 0.0 && p.k0 < N) ? p.k0 : 0;   // (kmin = N: first tick of a QP that inherits its factorisation -- its right-hand side is new)
     return p;
@@ -588,7 +600,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1; s0.ticks = 0; s0.fticks = 0; s0.tight = 0; s0.pad = 0;
             s0.snap_call = stp->snap_call; s0.snap_mu = stp->snap_mu; s0.snap_used = 0; s0.pad2 = 0;
             s0.mode = a.as_first ? 0.0 : 1.0; s0.cold_as = 0; s0.nviol = 0; s0.path = warm ? 10.0 : 0.0;
-            s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.uf_valid = 0;
+            s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.uf_valid = 0; s0.res_only = 0; s0.tbox = 0; s0.pad3 = 0; s0.pad4 = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
             if (status != ST_INIT && a.qpstat) {   // flagged without a solve: the statistics of this slot must not show the previous call's
@@ -720,7 +732,13 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         for (int o = lane; o < N * NX; o += 64) NUA[o] += alpha * W[o];
         it++;
         start_iter = true;
+    } else if (phase == P_POL2 && s.res_only != 0.0 && stp->pbox < RES_ONLY_TOL * qscale) {
+        // the un-refined solve met every condition of the certificate (element-wise ones checked by the look, equality residual just measured by
+        // the forward sweep): it is the answer.  k_qp_solve made the same test and did not run the backward sweep; CU, CL, NUP hold the solve.
+        polished = true; status = 0; s.kst = s.pst; s.kbox = s.tbox; s.ksign = s.psign; s.pbox = stp->pbox; s.res_only = 0.0;
+        phase = P_DONE;
     } else {
+        s.res_only = 0.0;
         // polish phases: zn = v - Pi g  (v was z0 - Pi r or zn - Pi r1); CU := zn, CL := accumulated E' nu
         const bool firstp = (phase == P_POL0);
         const double max_rounds = (s.warm == 1.0) ? (double)a.warm_rounds : (s.warm == 2.0 ? (double)a.as_rounds : 8.0);
@@ -819,6 +837,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         // violation and its set entry after the releases go to LDS (free between the sweeps), the neighbour tests of the local-maximum rule
         // read them there (pass B), and the new set is applied from LDS (pass C).  The unfused version below makes five dependent trips
         // (update zn, input pre-pass, plan, apply, ...): 45 us per tick with 3 waves per SIMD contending for memory, against 15 us alone.
+        double tvst = 0.0, tvbox = 0.0, tvsign = 0.0;      // the certificate's quantities of the un-refined solve (fused look only)
         auto fused_plan = [&](double tolv, double &nv, unsigned long long &hash) -> double {
             double *sV = sm, *sN = sm + n;
             int in_viol = 0;
@@ -834,6 +853,11 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                     CU[e] = zn; CL[e] = cl;
                 }
                 const double gr = el.pd * zn + el.q + cl, ac = ACT[e];
+                if (el.fr && ac == 0.0) tvst = fmax(tvst, fabs(gr));
+                if (el.fu) tvbox = fmax(tvbox, zn - el.hi);
+                if (el.fl) tvbox = fmax(tvbox, el.lo - zn);
+                if (ac > 0.0) tvsign = fmax(tvsign, gr);
+                if (ac < 0.0) tvsign = fmax(tvsign, -gr);
                 double nac = ac;
                 if (ac > 0.0 && gr > tolv) nac = 0.5;          // 0.5: released in this round (reads as "not in the set" below, counts as a change)
                 if (ac < 0.0 && -gr > tolv) nac = 0.5;
@@ -918,6 +942,14 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 const double pi = PI[e], zn = CU[e];
                 const double r1 = (pi != 0.0) ? el.pd * zn + el.q + CL[e] : 0.0;
                 V[e] = zn - pi * r1;
+            }
+            s.res_only = 0.0;
+            if (fused_look && a.n_refine <= 1 && s.pol_fail == 0.0) {
+                // fp64: the un-refined solve is normally accurate to rounding.  If it already meets the certificate's element-wise conditions, the next
+                // tick's forward sweep measures its equality residual and, when that is tiny too, nothing is left to refine (k_qp_solve skips the
+                // backward sweep; the accept test is at the top of the polish branch)
+                const double wst = wla::wave_max(tvst), wbox = wla::wave_max(tvbox), wsign = wla::wave_max(tvsign);
+                if (wst < ptol && wbox < ptol && wsign < ptol) { s.res_only = 1.0; s.pst = wst; s.tbox = wbox; s.psign = wsign; }
             }
             // n_refine refinement solves per polish: P_POL1 repeats until the last one, which runs as P_POL2 (s.pad counts them)
             if (phase == P_POL0) { s.pad = 0.0; phase = (a.n_refine <= 1) ? P_POL2 : P_POL1; }
@@ -1101,7 +1133,7 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
     extern __shared__ double sm[];
     phase_update<NX, NU>(a, 1, b, lane);
     wla::wsync_mem();
-    unsigned long long n_sweeps = 0, n_factor = 0, n_fstages = 0;
+    unsigned long long n_sweeps = 0, n_factor = 0, n_fstages = 0, n_bwd_skipped = 0;
 #ifdef QP_STAMP
     long long c_fwd = 0, c_bwd = 0, c_ph = 0, c_t0 = __builtin_readcyclecounter(), c_fwdf = 0;
 #define QSTAMP(acc) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc += t_ - c_last; c_last = t_; } while (0)
@@ -1130,14 +1162,20 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
             if (factor) { st->fticks += 1.0; if (phase == P_POL0) st->pol_fail = f; }
         }
         n_sweeps++; n_factor += factor ? 1 : 0; n_fstages += factor ? (unsigned long long)(a.N - fp.k0) : 0ULL;
+        // (wave-uniform) the sweep only had to measure the equality residual of a solve that is otherwise certified, and it is tiny: no backward
+        // sweep, phase_update accepts the un-refined solve (same test there)
+        const bool res_only_done = !MX && phase == P_POL2 && st->res_only != 0.0 && bmax < RES_ONLY_TOL * st->qscale;
+        n_bwd_skipped += res_only_done ? 1 : 0;
         wla::wsync_mem();
 #ifdef QP_STAMP
         if (factor) QSTAMP(c_fwdf); else QSTAMP(c_fwd);
 #endif
         asm volatile("" : "+s"(b));
         asm volatile("" : "+v"(lane));
-        if constexpr (MX) ne_backward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
-        else ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
+        if (!res_only_done) {
+            if constexpr (MX) ne_backward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
+            else ne_backward<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
+        }
         wla::wsync_mem();
         QSTAMP(c_bwd);
         asm volatile("" : "+s"(b));
@@ -1149,7 +1187,7 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
 #ifdef QP_STAMP
     if (lane == 0) { double *kk = a.kkt + (size_t)b * 8; kk[2] = (double)c_fwdf; kk[3] = (double)(double)n_fstages; kk[4] = (double)c_fwd; kk[5] = (double)c_bwd; kk[6] = (double)c_ph; kk[7] = (double)(__builtin_readcyclecounter() - c_t0); }
 #endif
-    if (lane == 0) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); atomicAdd(a.inst_launches + 2, n_fstages); atomicAdd(a.inst_launches + 3, n_sweeps ? 1ULL : 0ULL); }
+    if (lane == 0) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); atomicAdd(a.inst_launches + 2, n_fstages); atomicAdd(a.inst_launches + 3, n_sweeps ? 1ULL : 0ULL); if (n_bwd_skipped) atomicAdd(a.inst_launches + 4, n_bwd_skipped); }
 }
 
 // ------------------------------------------------------------------------------------------------

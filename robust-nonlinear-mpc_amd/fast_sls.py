@@ -209,7 +209,8 @@ class BatchedFastSLS:
         self.fwd_instance_sweeps = int(t[3])   # instance forward sweeps (= backward sweeps)
         self.fwd_factor_sweeps = int(t[4])     # ... of which factorising
         self.factor_stages = int(t[5])         # stages factorised
-        self.qp_solves = int(t[6])             # QP solves started by k_qp_solve launches
+        self.qp_solves = int(t[6])             # QP solves that ran (at least one block solve) in k_qp_solve launches
+        self.bwd_sweeps_skipped = int(t[7])    # block solves that ended after the forward sweep (residual check of an already certified solve)
         return t[0], int(t[1])
 
     def solve(self, x0, fetch=True):

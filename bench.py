@@ -87,7 +87,7 @@ def cpu_baseline(m, N, data, budget_s=10.0):
     v1, n1, t1, ok1 = run(1, 0.6 * budget_s)
     vc, nc, tc, okc = (v1, n1, t1, ok1) if cores == 1 else run(cores, budget_s)
     return {"value": vc, "unit": "QP solves/s", "cores": cores, "kind": "port", "single_thread_value": v1, "solved_frac": okc,
-            "sample": f"the QPs of the GPU's last timed step, first instances of rank 0, 1 RTI MPC step (2 QP + 1 sweep) each, OSQP-class restatement "
+            "sample": f"the QPs of the GPU's last timed step (first instances of rank 0 whose step the GPU solved), 1 RTI MPC step (2 QP + 1 sweep) each, OSQP-class restatement "
                       f"with upstream default settings + polish, C threads: {nc} instances on {cores} threads in {tc:.1f} s; {n1} instances on 1 thread "
                       f"in {t1:.1f} s"}
 
@@ -415,9 +415,11 @@ def main():
         cpu_data = None
         if args.workload == "closed_loop" and not args.no_cpu and world == 1:
             f0 = dev.cl[0].f
-            ncpu = min(f0.B, 1024)
-            cpu_data = {k: f0.get(k, shp)[:ncpu] for k, shp in (("A", (N, m.nx, m.nx)), ("Bm", (N, m.nx, m.nu)), ("c", (N, m.nx)), ("g", (N, m.ni)), ("gN", (m.ni_f,)),
-                                                                 ("q", (n_var,)), ("x0_arg", (m.nx,)))}
+            # the CPU gets the instances whose two QPs the GPU solved in that step (steps flagged infeasible at x0 cost neither side any work)
+            qs0 = f0.get("qp_stats", (2, 8), np.int32)
+            sel = np.flatnonzero((qs0[:, 0, 6] == 0) & (qs0[:, 1, 6] == 0))[:1024]
+            cpu_data = {k: f0.get(k, shp)[sel] for k, shp in (("A", (N, m.nx, m.nx)), ("Bm", (N, m.nx, m.nu)), ("c", (N, m.nx)), ("g", (N, m.ni)), ("gN", (m.ni_f,)),
+                                                               ("q", (n_var,)), ("x0_arg", (m.nx,)))}
         elif args.workload == "synthetic" and not args.no_cpu and world == 1:
             ncpu = min(B, 1024)
             cpu_data = {"A": batch["A"][:ncpu], "Bm": batch["B"][:ncpu], "c": batch["c"][:ncpu], "g": batch["g"][:ncpu], "gN": batch["gN"][:ncpu], "q": batch["q"][:ncpu],

@@ -50,6 +50,7 @@ struct slsqp_handle {
     int *status, *iters, *itnum, *has_prev, *conv, *alive, *mask, *success, *infeas, *counter;
     int *scp_active, *scp_success, *scp_iters, *pending_reset, *scp_upd; double *scp_dmax;
     int horizon_shifted = 0;
+    int *qp_diag = nullptr;     // QP_DIAG_SPAN builds only
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
     int *retry; int mx_retry, mx_retry_total;
     double *Kc, *Aclc;          // (B,N,nu,nx), (B,N,nx,nx): K_k and A_k + B_k K_k of the shared Riccati recursion (k_sweep_ric1 -> k_sweep_prop)
@@ -204,6 +205,10 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     reg("A", h->A, sizeof(double) * N * nx * nx); reg("Bm", h->Bm, sizeof(double) * N * nx * nu); reg("c", h->c, sizeof(double) * N * nx);
     reg("g", h->g, sizeof(double) * N * ni); reg("gN", h->gN, sizeof(double) * nif); reg("q", h->q, sizeof(double) * h->n); reg("pin_dual", h->pin_dual, sizeof(double) * nx);
     reg("primal_infeasibility", h->pinf, sizeof(double)); reg("qp_stats", h->qpstat, sizeof(int) * 16); reg("x0_arg", h->x0arg, sizeof(double) * nx);
+#ifdef QP_DIAG_SPAN
+    if (dalloc(h->owned, &h->qp_diag, B * 64)) return nullptr;
+    reg("qp_diag", h->qp_diag, sizeof(int) * 64);
+#endif
     return h;
 }
 
@@ -418,7 +423,7 @@ __global__ void k_mark_retry(int B, const int *run, const int *status, int *retr
 static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr, int stat_slot = 0, int snap_take = 0, int snap_use = 0,
                      int warm_shift = 0) {
     QpArgs a;
-    a.qpstat = h->qpstat; a.stat_slot = stat_slot;
+    a.qpstat = h->qpstat; a.stat_slot = stat_slot; a.diag = h->qp_diag;
     static const double snap_mu = getenv("SLSQP_SNAP_MU") ? atof(getenv("SLSQP_SNAP_MU")) : 1e-3;
     a.snap_take = snap_take; a.snap_use = snap_use && o->ipm_restart; a.snap_mu = snap_mu; a.call_id = h->call_id; a.as_first = o->as_first; a.as_rounds = o->as_rounds; a.as_max_viol = o->as_max_viol;
     { static const int ws = getenv("SLSQP_WARM_SHIFT") ? atoi(getenv("SLSQP_WARM_SHIFT")) : 1; a.warm_shift = ws ? warm_shift : 0; }

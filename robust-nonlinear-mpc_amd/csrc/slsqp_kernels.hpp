@@ -85,6 +85,7 @@ struct QpArgs {
     double call_id;           // identifies the fast-SLS call (a copy is only valid within the call that took it: same A, B, q)
     int as_first;             // 1: a cold solve first tries the active-set iteration from the empty set (the equality-constrained optimum of P_INIT)
     int as_rounds;            // rounds such an attempt may take (a warm one: warm_rounds)
+    int *diag;                // QP_DIAG_SPAN builds: (B,2,16,2) first / last stage whose set entry changed, per active-set round
     int warm_shift;           // 1: the first QP's warm set is the previous call's set moved one stage towards the start of the horizon (receding horizon)
     int as_max_viol;          // an attempt is abandoned when a solve leaves more violated bounds than this, or more than 2 x the previous round's + 8
     int n_refine;             // refinement solves per polish (1 in fp64, 3 with fp32 factorisations)
@@ -603,6 +604,9 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.uf_valid = 0; s0.res_only = 0; s0.tbox = 0; s0.pad3 = 0; s0.pad4 = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
+#ifdef QP_DIAG_SPAN
+            if (a.diag) for (int i = 0; i < 32; i++) a.diag[((size_t)b * 2 + a.stat_slot) * 32 + i] = -1;
+#endif
             if (status != ST_INIT && a.qpstat) {   // flagged without a solve: the statistics of this slot must not show the previous call's
                 int *qs = a.qpstat + ((size_t)b * 2 + a.stat_slot) * 8;
                 for (int i = 0; i < 8; i++) qs[i] = 0;
@@ -872,6 +876,9 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             wla::wsync();
             const bool any_in = wla::wave_or(in_viol) != 0;
             double changed = 0.0, kfirst = 1e9;
+#ifdef QP_DIAG_SPAN
+            double klast = -1.0;
+#endif
             unsigned long long hv = 0ULL;
 #pragma unroll 2
             for (int e = lane; e < n; e += 64) {
@@ -888,6 +895,9 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                     if (take) { nac = v > 0.0 ? 1.0 : -1.0; chg = true; }
                 }
                 if (chg) { changed += 1.0; kfirst = fmin(kfirst, (double)max(0, e / NZ - ((e % NZ) < NX ? 1 : 0))); }
+#ifdef QP_DIAG_SPAN
+                if (chg) klast = fmax(klast, (double)min(N - 1, e / NZ));
+#endif
                 if (nac != 0.0) {
                     unsigned long long x = (unsigned long long)(2 * e + (nac > 0.0 ? 1 : 0)) + 0x9E3779B97F4A7C15ULL;
                     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; hv ^= x ^ (x >> 31);
@@ -903,6 +913,13 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             hash = hv | 1ULL;
             nv = wla::wave_sum(viols);
             s.kmin = fmin(wla::wave_min(kfirst), (double)N);
+#ifdef QP_DIAG_SPAN
+            {
+                const double kl = wla::wave_max(klast);
+                const int r = (int)s.pol_round;
+                if (lane == 0 && a.diag && r < 16 && kl >= 0.0) { int *dg = a.diag + (((size_t)b * 2 + a.stat_slot) * 16 + r) * 2; dg[0] = (int)s.kmin; dg[1] = (int)kl; }
+            }
+#endif
             return wla::wave_sum(changed);
         };
         auto fused_apply = [&]() {

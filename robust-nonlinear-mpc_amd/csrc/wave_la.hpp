@@ -387,11 +387,17 @@ __device__ __forceinline__ int spd_inv_gj(const R *Y, int ld, R *Dinv, int ldi, 
 #pragma unroll
     for (int jb = 0; jb < T; jb++) {
         const int tri_jb = jb * (jb + 1) / 2, dl = tri_jb + jb;
-        // C_I = A_{I,J} (2x2): lane (bi, jb) if bi > jb, else lane (jb, bi) transposed;  C_L = A_{L,J} likewise.  Issued first so the
-        // crossbar round trip overlaps the dependent reciprocal chain of the pivot block below.
+        // One uniform update for every lane:  A <- m A - (C_I P^-1) C_L'  with C_I = A_{I,J}, C_L = A_{L,J} fetched through the crossbar.
+        // The diagonal lane (the only one pivot-row lanes read as C_I and pivot-column lanes read as C_L) sends -I instead of its block, and the
+        // lanes of the pivot row / column start from m = 0:  column: 0 - (A_IJ P^-1)(-I) = A_IJ P^-1;  row: 0 - (-P^-1) A_JL = P^-1 A_JL;
+        // diagonal: 0 - (-P^-1)(-I) = -P^-1.  (The pivot block itself travels through v_readlane below.)
+        const bool isD = (bi == jb) & (bj == jb), inRC = (bi == jb) | (bj == jb);
+        const R md = isD ? R(0) : R(1), cd = isD ? R(-1) : R(0), m = inRC ? R(0) : R(1);
+        const R s00 = fma(a00, md, cd), s01 = a01 * md, s10 = a10 * md, s11 = fma(a11, md, cd);
+        // Issued first so the crossbar round trip overlaps the dependent reciprocal chain of the pivot block below.
         const int srcI = (bi >= jb) ? tri_bi + jb : tri_jb + bi, srcL = (bj >= jb) ? tri_bj + jb : tri_jb + bj;
-        const R f00 = bperm_d(a00, srcI), f01 = bperm_d(a01, srcI), f10 = bperm_d(a10, srcI), f11 = bperm_d(a11, srcI);
-        const R g00 = bperm_d(a00, srcL), g01 = bperm_d(a01, srcL), g10 = bperm_d(a10, srcL), g11 = bperm_d(a11, srcL);
+        const R f00 = bperm_d(s00, srcI), f01 = bperm_d(s01, srcI), f10 = bperm_d(s10, srcI), f11 = bperm_d(s11, srcI);
+        const R g00 = bperm_d(s00, srcL), g01 = bperm_d(s01, srcL), g10 = bperm_d(s10, srcL), g11 = bperm_d(s11, srcL);
         __builtin_amdgcn_sched_barrier(0);
         // pivot block (uniform): P = [[pa, pb],[pb, pc]] from the diagonal lane; P^-1 by two scalar eliminations (as stable as 1x1 pivots)
         const R pa = readlane_d(a00, dl), pb = readlane_d(a10, dl), pc = readlane_d(a11, dl);
@@ -405,19 +411,10 @@ __device__ __forceinline__ int spd_inv_gj(const R *Y, int ld, R *Dinv, int ldi, 
         const bool tI = bi < jb, tL = bj < jb;
         const R ci00 = f00, ci01 = tI ? f10 : f01, ci10 = tI ? f01 : f10, ci11 = f11;
         const R cl00 = g00, cl01 = tL ? g10 : g01, cl10 = tL ? g01 : g10, cl11 = g11;
-        // general update: B -= (C_I P^-1) C_L'
         const R t00 = fma(ci00, q00, ci01 * q01), t01 = fma(ci00, q01, ci01 * q11);
         const R t10 = fma(ci10, q00, ci11 * q01), t11 = fma(ci10, q01, ci11 * q11);
-        const R n00 = fma(-t00, cl00, fma(-t01, cl01, a00)), n01 = fma(-t00, cl10, fma(-t01, cl11, a01));
-        const R n10 = fma(-t10, cl00, fma(-t11, cl01, a10)), n11 = fma(-t10, cl10, fma(-t11, cl11, a11));
-        // block column jb (rows below the pivot): B <- B P^-1 ; block row jb (cols left of the pivot): B <- P^-1 B
-        const R c00 = fma(a00, q00, a01 * q01), c01 = fma(a00, q01, a01 * q11), c10 = fma(a10, q00, a11 * q01), c11 = fma(a10, q01, a11 * q11);
-        const R w00 = fma(q00, a00, q01 * a10), w01 = fma(q00, a01, q01 * a11), w10 = fma(q01, a00, q11 * a10), w11 = fma(q01, a01, q11 * a11);
-        const bool isD = (bi == jb) & (bj == jb), inC = (bj == jb) & !isD, inR = (bi == jb) & !isD;
-        a00 = isD ? -q00 : (inC ? c00 : (inR ? w00 : n00));
-        a01 = isD ? -q01 : (inC ? c01 : (inR ? w01 : n01));
-        a10 = isD ? -q01 : (inC ? c10 : (inR ? w10 : n10));
-        a11 = isD ? -q11 : (inC ? c11 : (inR ? w11 : n11));
+        a00 = fma(a00, m, -fma(t00, cl00, t01 * cl01)); a01 = fma(a01, m, -fma(t00, cl10, t01 * cl11));
+        a10 = fma(a10, m, -fma(t10, cl00, t11 * cl01)); a11 = fma(a11, m, -fma(t10, cl10, t11 * cl11));
     }
     if (act) {   // Dinv = -swept, mirrored to the full matrix
         if (i0 < M && l0 < M) { Dinv[i0 * ldi + l0] = -a00; Dinv[l0 * ldi + i0] = -a00; }

@@ -50,6 +50,7 @@ struct slsqp_handle {
     int *status, *iters, *itnum, *has_prev, *conv, *alive, *mask, *success, *infeas, *counter;
     int *scp_active, *scp_success, *scp_iters, *pending_reset, *scp_upd; double *scp_dmax;
     int horizon_shifted = 0;
+    bool solve_timing_pending = false, pend_first = false; double pend_qp = 0, pend_sw = 0;
     int *qp_diag = nullptr;     // QP_DIAG_SPAN builds only
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
     int *retry; int mx_retry, mx_retry_total;
@@ -508,7 +509,19 @@ static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, cons
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
 
 // `active` (device, B ints or NULL = all): instances that take part in this call; the others keep every result array untouched.
-static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts, const int *active) {
+// timing of a solve whose launches have completed (the stream has been synchronised since): sums the event pairs solve_impl left behind
+static void finish_solve_timing(slsqp_handle *h) {
+    if (!h->solve_timing_pending) return;
+    harvest_kernel_events(h);
+    double acc_qp = h->pend_qp, acc_sw = h->pend_sw;
+    if (h->pend_first) { acc_qp += ev_ms(h->ev[1], h->ev[2]); acc_sw += ev_ms(h->ev[3], h->ev[4]); }
+    acc_qp += ev_ms(h->ev[8], h->ev[9]);
+    h->t_total = ev_ms(h->ev[0], h->ev[5]); h->t_qp = acc_qp; h->t_sweep = acc_sw;
+    h->solve_timing_pending = false;
+}
+
+// no_sync: return with the launches queued (the caller synchronises the stream later and then calls finish_solve_timing)
+static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts, const int *active, bool no_sync = false) {
     hipSetDevice(h->dev);
     if (h->general_G) return fail("general G: only the sweep-level boundary (slsqp_sweep) is available; the QP solver needs box constraints G = [I;-I]");
     if (!h->have_costs || !h->have_cons || !h->have_dyn) return fail("set_costs, set_constraints and update_dynamics must be called first");
@@ -583,17 +596,17 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     HIPCHK(hipEventRecord(h->ev[9], h->st));
     hipLaunchKernelGGL(k_finish, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->alive, h->infeas, h->success, active, h->pending_reset);
     HIPCHK(hipEventRecord(h->ev[5], h->st));
+    h->solve_timing_pending = true; h->pend_qp = acc_qp; h->pend_sw = acc_sw; h->pend_first = deferred;
+    if (no_sync) return 0;
     HIPCHK(hipStreamSynchronize(h->st));
-    harvest_kernel_events(h);
-    if (deferred) { acc_qp += ev_ms(h->ev[1], h->ev[2]); acc_sw += ev_ms(h->ev[3], h->ev[4]); }
-    acc_qp += ev_ms(h->ev[8], h->ev[9]);
-    h->t_total = ev_ms(h->ev[0], h->ev[5]); h->t_qp = acc_qp; h->t_sweep = acc_sw;
+    finish_solve_timing(h);
     return 0;
 }
 
 extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts) { return solve_impl(h, x0, loc, opts, nullptr); }
 
 extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms5) {
+    if (h->solve_timing_pending) { hipSetDevice(h->dev); hipStreamSynchronize(h->st); finish_solve_timing(h); }
     ms5[0] = h->t_total; ms5[1] = h->t_qp; ms5[2] = h->t_sweep; ms5[3] = h->t_total - h->t_qp - h->t_sweep; ms5[4] = h->t_jac;
     return 0;
 }
@@ -603,6 +616,7 @@ extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out8) {
     hipMemcpyAsync(il, h->inst_launches, sizeof(il), hipMemcpyDeviceToHost, h->st);
     hipMemsetAsync(h->inst_launches, 0, sizeof(il), h->st);
     hipStreamSynchronize(h->st);
+    finish_solve_timing(h);
     out8[0] = h->t_fwd; out8[1] = (double)h->n_fwd; out8[2] = (double)h->mx_retry_total; out8[3] = (double)il[0]; out8[4] = (double)il[1];
     out8[5] = (double)il[2]; out8[6] = (double)il[3]; out8[7] = (double)il[4];
     h->t_fwd = 0; h->n_fwd = 0; h->mx_retry_total = 0;
@@ -861,24 +875,26 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
     hipLaunchKernelGGL(k_fill_int, dim3(gbi), dim3(256), 0, h->st, h->scp_success, 0, B);
     hipLaunchKernelGGL(k_fill_int, dim3(gbi), dim3(256), 0, h->st, h->scp_iters, 0, B);
     double tj = 0;
+    bool timing_done = false;
     HIPCHK(hipEventRecord(h->ev[6], h->st));
     if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, nullptr)) return -1;
     HIPCHK(hipEventRecord(h->ev[7], h->st));
     for (int ii = 0; ii < max_it; ii++) {
         hipLaunchKernelGGL(k_cl_x0arg, dim3(64), dim3(256), 0, h->st, a);
-        if (solve_impl(h, h->x0arg, SLSQP_DEVICE, &o, h->scp_active)) return -1;      // ends with a stream synchronisation
-        tq += h->t_qp; ts += h->t_sweep; tt += h->t_total; tj += ev_ms(h->ev[6], h->ev[7]);
+        if (solve_impl(h, h->x0arg, SLSQP_DEVICE, &o, h->scp_active, /* no_sync */ true)) return -1;
         HIPCHK(hipMemsetAsync(h->counter + 2, 0, sizeof(int), h->st));
         ScpArgs sa{ii, converge ? 1 : 0, o.scp_eps, h->scp_active, h->scp_success, h->scp_iters, h->counter + 2, h->scp_dmax, h->scp_upd};
         hipLaunchKernelGGL(k_cl_scp_update, dim3(B), dim3(64), 0, h->st, a, sa);
         if (h->model_id == 0) hipLaunchKernelGGL((k_cl_infeas<0>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
         else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_infeas<1>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
         else hipLaunchKernelGGL((k_cl_infeas<2>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
-        if (ii + 1 == max_it) break;
+        if (ii + 1 == max_it) break;        // (the last iteration's timing is collected after the step's final synchronisation)
         int nact = 0;
         HIPCHK(hipMemcpyAsync(&nact, h->counter + 2, sizeof(int), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
-        if (nact == 0) break;
+        finish_solve_timing(h);
+        tq += h->t_qp; ts += h->t_sweep; tt += h->t_total; tj += ev_ms(h->ev[6], h->ev[7]);
+        if (nact == 0) { timing_done = true; break; }
         HIPCHK(hipEventRecord(h->ev[6], h->st));
         if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, h->scp_active)) return -1;   // update_jacobian for the next iteration (:138)
         HIPCHK(hipEventRecord(h->ev[7], h->st));
@@ -893,6 +909,7 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
     else hipLaunchKernelGGL((k_cl_shift_plant<2>), dim3(gb), dim3(64), 0, h->st, a, 0, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->st));
+    if (!timing_done) { finish_solve_timing(h); tq += h->t_qp; ts += h->t_sweep; tt += h->t_total; tj += ev_ms(h->ev[6], h->ev[7]); }
     h->t_qp = tq; h->t_sweep = ts; h->t_total = tt; h->t_jac = tj;
     h->cl_steps++;
     return 0;

@@ -31,7 +31,7 @@ with open(sys.argv[2], "w") as f:
     for i, r in enumerate(rows):
         f.write(f"{i},{int(r['Start_Timestamp']) - t0},{int(r['End_Timestamp']) - int(r['Start_Timestamp'])},{r.get('Grid_Size_X', r.get('Grid_Size', ''))}\n")
 PY
-  python3 scripts/pmc_traffic.py $out/pmc_s$sl $out/pmc_traffic_s$sl.json "$(git rev-parse --short HEAD 2>/dev/null || echo worktree)" "$cmd --slices $sl" $((2 * 5 * sl)) > /dev/null
+  python3 scripts/pmc_traffic.py $out/pmc_s$sl $out/pmc_traffic_s$sl.json "$(cat $root/profiles/r02/BUILD 2>/dev/null || echo worktree)" "$cmd --slices $sl" $((2 * 5 * sl)) > /dev/null
 done
 python3 scripts/pmc_sq.py $out/pmc_sq $out/pmc_sq.json > $out/pmc_sq_summary.txt 2>&1
 # keep what is copied back small: the raw per-dispatch csv files stay on the box

@@ -400,7 +400,9 @@ def main():
         # dominant kernel: k_qp_solve; time = HIP events around every launch on the launching stream (opts.time_kernels), work = device counters.
         # The kernel is bound by vector-ALU instruction issue: its roof is the fp64 peak (matrix = vector = 78.6 TFLOP/s).
         rb = roof_block(k_ms, k_launches, inst_sweeps, fact_stages, qp_solves)
-        traffic, tsrc = read_traffic("pmc_traffic.json", "k_qp_solve_bytes_per_launch")
+        # the committed PMC passes are of the default command: attach them only to a run of that workload (and slice count)
+        pmc_ok = headline and args.precision == 0 and args.x0_scale is None and args.steps == 5 and args.warmup == 1
+        traffic, tsrc = read_traffic("pmc_traffic.json", "k_qp_solve_bytes_per_launch") if (pmc_ok and n_sl == 3) else (None, "no PMC pass of this configuration in profiles/r02")
         calls = args.steps * n_sl
         sweep_flop = SWEEP_MFLOP * 1e6 * (m.nx / 17.0) ** 3 * (N / 20.0) ** 2
         step_tf = (fact_stages * kf + 2.0 * inst_sweeps * N * ks + args.steps * B * sweep_flop) / dt / 1e12
@@ -442,7 +444,7 @@ def main():
                     ms1, n1, sw1, _ = one.kernel_timing()
                     fs1, qs1 = one.factor_stages, one.qp_solves
                     one.close()
-                    tr1, ts1 = read_traffic("pmc_traffic_single_slice.json", "k_qp_solve_bytes_per_launch")
+                    tr1, ts1 = read_traffic("pmc_traffic_single_slice.json", "k_qp_solve_bytes_per_launch") if pmc_ok else (None, "no PMC pass of this configuration in profiles/r02")
                     out["roofline"]["single_slice"] = dict(roof_block(ms1, n1, sw1, fs1, qs1), traffic=tr1, traffic_source=ts1, ms_per_step=1e3 * dt1 / args.steps,
                                                            gpu_ms_per_step={k: a1[0][k] / args.steps for k in a1[0]},
                                                            note="same closed-loop steps with the whole batch as one slice, after the timed region")

@@ -18,11 +18,13 @@ for k, v in acc.items():
         d["lds_active_frac_of_wave_cycles"] = v.get("SQ_ACTIVE_INST_LDS", 0.0) / wc
         d["wait_any_frac_of_wave_cycles"] = v.get("SQ_WAIT_ANY", 0.0) / wc
         d["wait_inst_any_frac_of_wave_cycles"] = v.get("SQ_WAIT_INST_ANY", 0.0) / wc
+    if v.get("SQ_LDS_IDX_ACTIVE", 0.0) > 0:
+        d["lds_bank_conflict_frac_of_lds_active"] = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"]
     bc = v.get("SQ_BUSY_CYCLES", 0.0)
     if bc > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
         d["mfma_busy_cycles_per_sq_busy_cycle"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / bc
     out[k] = d
 json.dump({"source": "rocprofv3 --pmc (one SQ pass), command: python3 bench.py --steps 5 --warmup 1 --no-cpu --no-secondary --slices 1", "kernels": out}, open(dst, "w"), indent=1)
-for k in ("k_qp_solve", "k_ne_fwd", "k_ne_bwd_phase", "k_sweep", "k_lin_jac"):
+for k in ("k_qp_solve", "k_sweep_prop", "k_sweep_ric1", "k_lin_tan", "k_lin_val"):
     if k in out:
         print(k, {a: (round(b, 4) if isinstance(b, float) and b < 10 else b) for a, b in out[k].items()})

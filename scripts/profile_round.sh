@@ -15,7 +15,9 @@ for sl in 3 1; do
   done
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/pmc_sq -o p -- $cmd --slices 1 > $out/pmc_sq.log 2>&1 || echo "sq pass failed"
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/pmc_lds -o p -- $cmd --slices 1 > $out/pmc_lds.log 2>&1 || echo "lds pass failed"
 cd $root
+python3 scripts/pmc_sq.py $out/pmc_lds $out/pmc_lds.json > $out/pmc_lds_summary.txt 2>&1
 for sl in 3 1; do
   f=$(ls $out/stats_s$sl/*kernel_stats.csv $out/stats_s$sl/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp $f $out/kernel_stats_s$sl.csv
@@ -35,6 +37,6 @@ PY
 done
 python3 scripts/pmc_sq.py $out/pmc_sq $out/pmc_sq.json > $out/pmc_sq_summary.txt 2>&1
 # keep what is copied back small: the raw per-dispatch csv files stay on the box
-rm -rf $out/stats_s3 $out/stats_s1 $out/pmc_s3 $out/pmc_s1 $out/pmc_sq
+rm -rf $out/stats_s3 $out/stats_s1 $out/pmc_s3 $out/pmc_s1 $out/pmc_sq $out/pmc_lds
 ls -la $out
 head -12 $out/kernel_stats_s3.csv

@@ -172,25 +172,36 @@ __device__ __forceinline__ void gemm_mfma(const double *A, int lda, const double
         for (int r = 0; r < 4; r++) acc[r] = fma(a_at(min(lk + 4 * r, MC - 1), 16), b16, acc[r]);
     }
     // every load (core, rank-1, border) is issued before the first store, so C may be A or B itself: the LDS operations of the one wave
-    // of the workgroup execute in program order
-    constexpr int NROW = (M == 17) ? N : 0, NCOL = (N == 17) ? MC : 0;
-    double sb = 0.0;
-    int ib = 0, jb2 = 0;
-    if constexpr (M == 17 || N == 17) {
-        const bool isrow = lane < NROW;
-        ib = isrow ? 16 : min(lane - NROW, MC - 1); jb2 = isrow ? min(lane, N - 1) : 16;
-        if (lane < NROW + NCOL) {
-            sb = ADD ? D[ib * ldd + jb2] : 0.0;
+    // of the workgroup execute in program order.
+    // Border entries: row 16 of the result (N entries, with the corner) and column 16 (MC entries) are vector-matrix / matrix-vector products;
+    // each is split three ways over k across lane groups (lane = entry + count * g) and combined through the crossbar: 6 dependent FMAs and
+    // 12 LDS reads per lane instead of the 17 / 34 of one lane per entry.
+    double srow = 0.0, scol = 0.0;
+    if constexpr (M == 17) {
+        const int g = lane / N, j = lane - g * N;
+        double v = 0.0;
+        if (g < 3) {
+            if (ADD && g == 0) v = D[16 * ldd + j];
 #pragma unroll
-            for (int k = 0; k < K; k++) sb = fma(a_at(ib, k), b_at(k, jb2), sb);
+            for (int q = 0; q < (K + 2) / 3; q++) { const int k = 3 * q + g; if (k < K) v = fma(a_at(16, k), b_at(k, j), v); }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        srow = v + __shfl(v, lane + N) + __shfl(v, lane + 2 * N);
     }
+    if constexpr (N == 17) {
+        const int g = lane / MC, i = lane - g * MC;
+        double v = 0.0;
+        if (g < 3) {
+            if (ADD && g == 0) v = D[i * ldd + 16];
+#pragma unroll
+            for (int q = 0; q < (K + 2) / 3; q++) { const int k = 3 * q + g; if (k < K) v = fma(a_at(i, k), b_at(k, 16), v); }
+        }
+        scol = v + __shfl(v, lane + MC) + __shfl(v, lane + 2 * MC);
+    }
+    if constexpr (M == 17 || N == 17) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int r = 0; r < 4; r++) { const int i = lk + 4 * r; if (i < MC && li < NC) C[i * ldc + li] = acc[r]; }
-    if constexpr (M == 17 || N == 17) {
-        if (lane < NROW + NCOL) C[ib * ldc + jb2] = sb;
-    }
+    if constexpr (M == 17) { if (lane < N) C[16 * ldc + lane] = srow; }
+    if constexpr (N == 17) { if (lane < MC) C[lane * ldc + 16] = scol; }
 }
 
 // Lower triangle (i >= j) of  Y = M1 A' + B diag(piu) B' - T M1' + diag(d) ,  all NX x NX (B: NX x NU), 2x2 blocks, one pass.

@@ -686,8 +686,16 @@ def test_one_infeasible_instance_does_not_fail_the_batch():
     clean = run_gpu_fastsls(insts, rti_steps=1)
     bad = [make_instance("pendulum", s, 0.5) for s in range(4)]
     bad[1].x0_arg = bad[1].x0_arg + 100.0
-    out = run_gpu_fastsls(bad, rti_steps=1)
+    from problems import make_gpu_solver
+    f = make_gpu_solver(bad)
+    out = run_gpu_fastsls(bad, rti_steps=1, solver=f)
+    qs = f.get("qp_stats", (2, 8), np.int32)
+    f.close()
     assert not out["success"][1] and out["status"][1] == 2
+    # per-QP statistics: the first QP of instance 1 is flagged without a block solve (status 2), its last QP never runs (status -1);
+    # the others ran both and certified them (these are the statuses bench.py's `value` counts by)
+    assert qs[1, 0, 6] == 2 and qs[1, 0, 1] == 0 and qs[1, 1, 6] == -1
+    assert np.all(qs[[0, 2, 3], :, 6] == 0) and np.all(qs[[0, 2, 3], :, 1] >= 1)
     for b in (0, 2, 3):
         assert out["success"][b]
         assert np.array_equal(out["primal_vec"][b], clean["primal_vec"][b])

@@ -287,3 +287,20 @@ def test_closed_loop_oracle_back_ends_agree(model):
     assert np.max(np.abs(r1["primal_vec"] - r2["primal_vec"])) < 1e-7 * max(1.0, np.abs(r1["primal_vec"]).max())
     assert np.max(np.abs(r1["dual_vec"] - r2["dual_vec"])) < 1e-6 * max(1.0, np.abs(r1["dual_vec"]).max())
     assert np.allclose(r1["backoff"], r2["backoff"], rtol=1e-7, atol=1e-10)
+
+
+def test_bench_qp_statistics_are_over_the_solves_that_ran():
+    """bench.py's per-QP figures: solves flagged at x0 (status 2) and solves an instance took no part in (status -1) are reported as
+    fractions and left out of the iteration statistics."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    st = np.zeros((2, 4, 2, 8), dtype=np.int32)            # (steps, B, slot, 8)
+    st[..., 1] = 5; st[..., 3] = 3; st[..., 5] = 2
+    st[0, 1, 0] = [0, 0, 0, 0, 0, 0, 2, 0]; st[0, 1, 1] = [0, 0, 0, 0, 0, 0, -1, 0]      # instance 1, step 0: flagged, second QP not run
+    st[1, 2, 1] = [0, 0, 0, 0, 0, 0, 2, 0]                                                # instance 2, step 1: tightened QP flagged
+    out = bench.qp_statistics([st[0], st[1]])
+    assert out["qp1"]["infeasible_x0_frac"] == 1 / 8 and out["qp1"]["not_run_frac"] == 0 and out["qp1"]["ran_frac"] == 7 / 8
+    assert out["qp2"]["infeasible_x0_frac"] == 1 / 8 and out["qp2"]["not_run_frac"] == 1 / 8 and out["qp2"]["ran_frac"] == 6 / 8
+    assert out["qp1"]["block_solves_mean"] == 5 and out["qp2"]["block_solves_mean"] == 5 and out["qp2"]["certified_frac"] == 1.0
+    assert out["qp2"]["active_inequalities"]["histogram_per_step"]["counts"][0][1] == 3        # three solves of step 0 ran, 3 active rows each

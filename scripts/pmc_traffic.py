@@ -1,4 +1,4 @@
-"""Turn the FETCH_SIZE / WRITE_SIZE passes of scripts/pmc.sh into profiles/rNN/pmc_traffic.json (bytes per launch of every
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of scripts/profile_round.sh into profiles/rNN/pmc_traffic.json (bytes per launch of every
 kernel).  FETCH_SIZE / WRITE_SIZE are reported in KiB (rocprofv3); on gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream
 (MI355X_MICROARCH.md, HBM section): both the raw and the doubled figure are stored."""
 import csv, glob, json, sys, collections
@@ -21,7 +21,7 @@ for k, v in acc.items():
     fetch, write = v.get("FETCH_SIZE", 0.0) * 1024 / nf, v.get("WRITE_SIZE", 0.0) * 1024 / nw
     out[k] = {"launches": nf, "fetch_bytes_per_launch_raw": fetch, "fetch_bytes_per_launch_x2": 2 * fetch, "write_bytes_per_launch": write}
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), command: " + cmd, "build": build, "kernels": out}
-for kn in ("k_ne_fwd", "k_qp_solve", "k_sweep", "k_lin_jac"):
+for kn in ("k_qp_solve", "k_sweep_prop", "k_sweep_ric1", "k_lin_tan"):
     if kn in out:
         res[kn + "_bytes_per_launch"] = out[kn]["fetch_bytes_per_launch_x2"] + out[kn]["write_bytes_per_launch"]
 if tail_n > 0 and "k_qp_solve" in per_disp:

@@ -376,6 +376,36 @@ def test_mixed_precision_matches_fp64_and_oracle(model, B):
     f.close()
 
 
+@pytest.mark.parametrize("model,B", [("quadrotor", 2048), ("rocket", 4096)])
+def test_mixed_precision_tolerance_sweep_at_baseline_batch_sizes(model, B):
+    """BASELINE config 3 at its own sizes (quadrotor B=2048, rocket B=4096, N=20): fp32 factorisations against fp64 for the loosest and a tight
+    interior-point tolerance of the sweep; every instance certified by the fp64 KKT certificate and equal to the fp64 result to 1e-6."""
+    from robust_nonlinear_mpc_amd import BatchedFastSLS, make_batch
+    batch = make_batch(model, os.path.join(GOLDEN, {"quadrotor": "sweep_quadrotor_N20_s0.npz", "rocket": "sweep_rocket_N20_s0.npz"}[model]), B, seed=3)
+    m, N = batch["model"], batch["N"]
+    f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=B)
+    f.update_dynamics_list(batch["A"], batch["B"], batch["E"], batch["g"], batch["gN"], batch["c"])
+    f.update_linear_cost(batch["q"])
+    x0 = batch["x0_arg"]
+    ub, lb = f.get("ubg", (f.mb,)), f.get("lbg", (f.mb,))
+    f.qp_update_data_vec(batch["q"], np.concatenate([lb, -x0 - 1e-10], axis=1), np.concatenate([ub, -x0 + 1e-10], axis=1))
+    f.opts.warm_start = 0
+    f.opts.precision, f.opts.qp_eps = 0, 1e-9
+    xr, yr, st, _, _ = f.qp_solve()
+    assert (st == 0).all()
+    qn = max(1.0, np.abs(batch["q"]).max())
+    for eps in (1e-3, 1e-6):
+        f.opts.precision, f.opts.qp_eps = 1, eps
+        x, y, st, _, _ = f.qp_solve()
+        kk = f.get("kkt", (8,))
+        assert (st == 0).all(), (eps, np.bincount(st))
+        assert kk[:, :3].max() < 1e-8 * qn
+        err = np.abs(x - xr).max(axis=1) / np.maximum(1e-300, np.abs(xr).max(axis=1))
+        assert err.max() < 1e-6, (eps, int(err.argmax()), err.max())
+        assert (np.abs(y - yr).max(axis=1) < 1e-5 * np.maximum(1.0, np.abs(yr).max(axis=1))).all()
+    f.close()
+
+
 def test_osqp_generated_stand_in_module():
     """Level-2 switch: the module-level singleton the reference drives as `osqp_generated`
     (QP._cg_push_updates qp_jit.py:671-698, QP.solve :449-470): update_data_mat(P_x=, A_x=) -> 0, update_data_vec(q, l, u) -> 0,

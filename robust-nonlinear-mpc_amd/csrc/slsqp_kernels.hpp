@@ -1909,11 +1909,10 @@ __global__ __launch_bounds__(64, 4) void k_sweep_prop(SweepSharedArgs aa) {
         for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) sK[o] = rK[r]; }
         wla::wsync();
         if (k + 1 < N) fetch2(k + 1);
-#if SWEEP_MFMA
-        if constexpr (NX >= 13) wla::gemm_mfma<NU, NW, NX, false, false>(sK, NX, Pc, NW, sPu, NW, lane);
-        else
-#endif
-        wla::gemm_blk<NU, NW, NX, false, false, 1, 2, false>(sK, NX, Pc, NW, sPu, NW, 1.0, lane);  // Phi_u = K Phi_x
+        // Phi_u = K Phi_x and Phi_{k+1} = (A + B K) Phi_k: on the matrix core both at once (independent MFMA chains, Phi_k's operand read once)
+        constexpr bool PAIR = (SWEEP_MFMA != 0) && NX >= 13;
+        if constexpr (PAIR) wla::gemm_mfma_pair<NU, NX, NW, NX>(sK, NX, sAcl, NX, Pc, NW, sPu, NW, Pn, NW, lane);
+        else wla::gemm_blk<NU, NW, NX, false, false, 1, 2, false>(sK, NX, Pc, NW, sPu, NW, 1.0, lane);  // Phi_u = K Phi_x
         wla::wsync();
         {
             const int g3 = lane / NZ, rw = lane - g3 * NZ;
@@ -1932,11 +1931,7 @@ __global__ __launch_bounds__(64, 4) void k_sweep_prop(SweepSharedArgs aa) {
                 bo[lane] = s; bo[NZ + lane] = s;
             }
         }
-#if SWEEP_MFMA
-        if constexpr (NX >= 13) wla::gemm_mfma<NX, NW, NX, false, false>(sAcl, NX, Pc, NW, Pn, NW, lane);        // Phi_{k+1} = Acl Phi_k
-        else
-#endif
-        wla::gemm_blk<NX, NW, NX, false, false, 3, 2, false>(sAcl, NX, Pc, NW, Pn, NW, 1.0, lane);
+        if constexpr (!PAIR) wla::gemm_blk<NX, NW, NX, false, false, 3, 2, false>(sAcl, NX, Pc, NW, Pn, NW, 1.0, lane);   // Phi_{k+1} = Acl Phi_k
         wla::wsync();
         double *t = Pc; Pc = Pn; Pn = t;
     }

@@ -204,6 +204,71 @@ __device__ __forceinline__ void gemm_mfma(const double *A, int lda, const double
     if constexpr (N == 17) { if (lane < MC) C[lane * ldc + 16] = scol; }
 }
 
+// Two products with one right-hand operand, for the SLS propagation step:  Cu (MU x N) = Ku (MU x K) P  and  Cx (MX x N) = Ax (MX x K) P,
+// P (K x N) shared.  Same arithmetic as two gemm_mfma calls (core: four MFMAs each, 17th k as a rank-1 term, 17th row / column as three-way
+// split vector products), but the two accumulation chains are independent and interleave on the matrix pipe, and P's operand is read once.
+// MU <= 16; MX, N, K <= 17; no transposes; all 64 lanes active; Cu, Cx must not alias P.
+template <int MU, int MX, int N, int K>
+__device__ __forceinline__ void gemm_mfma_pair(const double *Ku, int ldk, const double *Ax, int lda, const double *P, int ldp, double *Cu, int ldcu, double *Cx,
+                                               int ldcx, int lane) {
+    static_assert(MU <= 16 && MX <= 17 && N <= 17 && K <= 17, "one 16x16 tile plus one border row / column / k");
+    constexpr int MUC = MU, MXC = MX < 16 ? MX : 16, NC = N < 16 ? N : 16, KC = K < 16 ? K : 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int iu = min(li, MUC - 1), ix = min(li, MXC - 1), jb = min(li, NC - 1);
+    mfma_d4 au = {0.0, 0.0, 0.0, 0.0}, ax = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k0 = 0; k0 < KC; k0 += 4) {
+        const int k = k0 + lk, kc = min(k, KC - 1);
+        const bool kok = k < KC;
+        const double bv = (li < NC && kok) ? P[kc * ldp + jb] : 0.0;
+        au = __builtin_amdgcn_mfma_f64_16x16x4f64((li < MUC && kok) ? Ku[iu * ldk + kc] : 0.0, bv, au, 0, 0, 0);
+        ax = __builtin_amdgcn_mfma_f64_16x16x4f64((li < MXC && kok) ? Ax[ix * lda + kc] : 0.0, bv, ax, 0, 0, 0);
+    }
+    if constexpr (K == 17) {
+        const double b16 = P[16 * ldp + jb];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            au[r] = fma(Ku[min(lk + 4 * r, MUC - 1) * ldk + 16], b16, au[r]);
+            ax[r] = fma(Ax[min(lk + 4 * r, MXC - 1) * lda + 16], b16, ax[r]);
+        }
+    }
+    double srow = 0.0, scx = 0.0, scu = 0.0;
+    if constexpr (MX == 17) {       // row 16 of Cx (with the corner)
+        const int g = lane / N, j = lane - g * N;
+        double v = 0.0;
+        if (g < 3) {
+#pragma unroll
+            for (int q = 0; q < (K + 2) / 3; q++) { const int k = 3 * q + g; if (k < K) v = fma(Ax[16 * lda + k], P[k * ldp + j], v); }
+        }
+        srow = v + __shfl(v, lane + N) + __shfl(v, lane + 2 * N);
+    }
+    if constexpr (N == 17) {        // column 16 of Cx (rows < 16) and of Cu, in one pass: entries MXC + MUC <= 21, three lane groups
+        constexpr int NE = MXC + MUC;
+        static_assert(3 * NE <= 64, "three lane groups");
+        const int g = lane / NE, e = lane - g * NE;
+        const double *row = (e < MXC) ? Ax + e * lda : Ku + (e - MXC) * ldk;
+        double v = 0.0;
+        if (g < 3) {
+#pragma unroll
+            for (int q = 0; q < (K + 2) / 3; q++) { const int k = 3 * q + g; if (k < K) v = fma(row[k], P[k * ldp + 16], v); }
+        }
+        const double t = v + __shfl(v, lane + NE) + __shfl(v, lane + 2 * NE);
+        scx = t; scu = t;
+    }
+    if constexpr (MX == 17 || N == 17) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int i = lk + 4 * r;
+        if (i < MUC && li < NC) Cu[i * ldcu + li] = au[r];
+        if (i < MXC && li < NC) Cx[i * ldcx + li] = ax[r];
+    }
+    if constexpr (MX == 17) { if (lane < N) Cx[16 * ldcx + lane] = srow; }
+    if constexpr (N == 17) {
+        if (lane < MXC) Cx[lane * ldcx + 16] = scx;
+        else if (lane < MXC + MUC) Cu[(lane - MXC) * ldcu + 16] = scu;
+    }
+}
+
 // Lower triangle (i >= j) of  Y = M1 A' + B diag(piu) B' - T M1' + diag(d) ,  all NX x NX (B: NX x NU), 2x2 blocks, one pass.
 // useT = false drops the T term.  Only the lower triangle of Y is written (the Cholesky reads nothing else).
 template <int NX, int NU, typename R>

@@ -401,7 +401,7 @@ def main():
         # The kernel is bound by vector-ALU instruction issue: its roof is the fp64 peak (matrix = vector = 78.6 TFLOP/s).
         rb = roof_block(k_ms, k_launches, inst_sweeps, fact_stages, qp_solves)
         # the committed PMC passes are of the default command: attach them only to a run of that workload (and slice count)
-        pmc_ok = headline and args.precision == 0 and args.x0_scale is None and args.steps == 5 and args.warmup == 1
+        pmc_ok = headline and args.precision == 0 and args.x0_scale is None      # (the passes timed closed-loop steps 1..5: --steps 5 --warmup 1)
         traffic, tsrc = read_traffic("pmc_traffic.json", "k_qp_solve_bytes_per_launch") if (pmc_ok and n_sl == 3) else (None, "no PMC pass of this configuration in profiles/r02")
         calls = args.steps * n_sl
         sweep_flop = SWEEP_MFLOP * 1e6 * (m.nx / 17.0) ** 3 * (N / 20.0) ** 2

@@ -92,7 +92,8 @@ void slsqp_destroy(slsqp_handle *h);
    Host pointers. Batch-constant. */
 int slsqp_set_costs(slsqp_handle *h, const double *Q, const double *R, const double *Qf, const double *Q_reg,
                     const double *R_reg, const double *Q_reg_f);
-/* G (ni,nx+nu), Gf (ni_f,nx), gf (ni_f): host pointers; G,Gf must be [I;-I]. gf is the RAW terminal bound that the
+/* G (ni,nx+nu), Gf (ni_f,nx), gf (ni_f): host pointers.  G = [I;-I], Gf = [I;-I] (every plant of the reference) enables all entry points;
+   any other G / Gf is accepted for the sweep-level boundary (slsqp_sweep) only -- the QP-level entry points then refuse.  gf is the RAW terminal bound that the
    tightened QP uses (fast_SLS_jit.py:524,568). */
 int slsqp_set_constraints(slsqp_handle *h, const double *G, const double *Gf, const double *gf);
 

@@ -184,6 +184,10 @@ int slsqp_last_timing(slsqp_handle *h, double *ms5);
    first changed one on), [6] QP solves (instances x launches of k_qp_solve), [7] reserved; resets the accumulators.  out must hold 8 doubles. */
 int slsqp_kernel_timing(slsqp_handle *h, double *out8);
 void *slsqp_stream(slsqp_handle *h); /* hipStream_t, for callers that share device buffers */
+/* Diagnostic: one wavefront runs one of the wave-level building blocks of the kernels (csrc/wave_la.hpp: the MFMA block products, the fused
+   product pair of the SLS propagation, the Gauss-Jordan SPD inverse, the D_k assembly) on packed row-major host operands; (nx,nu) = (17,4)
+   or (13,4).  Cases and operand order: slsqp_api.hip, k_selftest.  Used by tests/test_gpu_parity.py::test_wave_level_building_blocks. */
+int slsqp_selftest(int nx, int nu, int which, const double *in, int n_in, double *out, int n_out);
 
 #ifdef __cplusplus
 }

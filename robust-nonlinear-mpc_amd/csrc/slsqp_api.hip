@@ -1019,3 +1019,50 @@ extern "C" int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta
     HIPCHK(hipStreamSynchronize(h->st));
     return 0;
 }
+
+
+// ---- self-test of the wave-level building blocks (wave_la.hpp) ---------------------------------------------------
+// One wave runs one primitive on operands the caller supplies; tests/test_gpu_parity.py compares with numpy.  `in` / `out` are packed
+// row-major matrices in the order given per case below; device scratch is allocated per call (diagnostic entry point, not a hot path).
+template <int NX, int NU>
+__global__ __launch_bounds__(64) void k_selftest(int which, const double *in, double *out, int n_in, int n_out) {
+    extern __shared__ double sm[];
+    const int lane = threadIdx.x;
+    constexpr int MM = NX * NX, NB = NX * NU;
+    double *I0 = sm, *O0 = sm + n_in;
+    for (int o = lane; o < n_in; o += 64) I0[o] = in[o];
+    for (int o = lane; o < n_out; o += 64) O0[o] = 0.0;
+    wla::wsync();
+    if (which == 0) wla::gemm_mfma<NX, NX, NX, false, false>(I0, NX, I0 + MM, NX, O0, NX, lane);                                   // A B
+    else if (which == 1) wla::gemm_mfma<NX, NX, NX, true, false>(I0, NX, I0 + MM, NX, O0, NX, lane);                                // A' B
+    else if (which == 2) wla::gemm_mfma<NU, NX, NX, true, false>(I0, NU, I0 + NB, NX, O0, NX, lane);                                // Bm' S   (in: Bm NX x NU, S NX x NX)
+    else if (which == 3) wla::gemm_mfma<NX, NX, NX, false, false, false, true>(I0, NX, I0 + MM, NX, O0, NX, lane, nullptr, 0, I0 + 2 * MM);   // A diag(s) B
+    else if (which == 4) wla::gemm_mfma<NX, NX, NU, false, false, true>(I0, NU, I0 + NB, NX, O0, NX, lane, I0 + 2 * NB, NX);        // D + Bm K  (in: Bm, K NU x NX, D NX x NX)
+    else if (which == 5) wla::gemm_mfma_pair<NU, NX, NX, NX>(I0, NX, I0 + NB, NX, I0 + NB + MM, NX, O0, NX, O0 + NB, NX, lane);     // K P | A P (in: K NU x NX, A, P)
+    else if (which == 6) { const int f = wla::spd_inv_gj<NX>(I0, NX, O0, NX, (double *)nullptr, lane); if (lane == 0) O0[MM] = (double)f; }   // inverse of the SPD matrix whose lower triangle is given
+    else if (which == 7) {   // lower(Y) = A diag(pix) A' + B diag(piu) B' - T (A diag(pix))' + diag(d) + delta    (in: A, B, T, pix, piu, d)
+        const double *A = I0, *Bm = I0 + MM, *T = I0 + MM + NB, *pix = T + MM, *piu = pix + NX, *d = piu + NU;
+        if constexpr (NX >= 5) wla::build_Y_mfma<NX, NU>(A, pix, Bm, piu, T, true, d, 1e-13, O0, lane);
+    }
+    wla::wsync();
+    for (int o = lane; o < n_out; o += 64) out[o] = O0[o];
+}
+
+extern "C" int slsqp_selftest(int nx, int nu, int which, const double *in, int n_in, double *out, int n_out) {
+    if (n_in <= 0 || n_out <= 0 || n_in + n_out > 4000) return fail("selftest: operand sizes");
+    double *din = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc(&din, sizeof(double) * n_in));
+    if (hipMalloc(&dout, sizeof(double) * n_out) != hipSuccess) { hipFree(din); return fail("selftest: hipMalloc"); }
+    int rc = 0;
+    if (hipMemcpy(din, in, sizeof(double) * n_in, hipMemcpyHostToDevice) != hipSuccess) rc = -1;
+    const size_t lds = sizeof(double) * (size_t)(n_in + n_out);
+    if (!rc) {
+        if (nx == 17 && nu == 4) hipLaunchKernelGGL((k_selftest<17, 4>), dim3(1), dim3(64), lds, 0, which, din, dout, n_in, n_out);
+        else if (nx == 13 && nu == 4) hipLaunchKernelGGL((k_selftest<13, 4>), dim3(1), dim3(64), lds, 0, which, din, dout, n_in, n_out);
+        else rc = -2;
+    }
+    if (!rc && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, dout, sizeof(double) * n_out, hipMemcpyDeviceToHost) != hipSuccess)) rc = -1;
+    hipFree(din); hipFree(dout);
+    if (rc == -2) return fail("selftest: (nx, nu) must be (17, 4) or (13, 4)");
+    return rc ? fail("selftest: HIP error") : 0;
+}

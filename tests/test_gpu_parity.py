@@ -784,3 +784,51 @@ def test_full_size_batches_properties(model, B):
     assert np.array_equal(r1["primal"], r2["primal"]) and np.array_equal(r1["backoff"], r2["backoff"])
     assert np.array_equal(r1["primal"], r3["primal"][::-1]) and np.array_equal(r1["backoff"], r3["backoff"][::-1])
     assert (r1["backoff"][:, :, : m.nx] > 0).all()      # tightening really happened
+
+
+@pytest.mark.parametrize("nx,nu", [(17, 4), (13, 4)])
+def test_wave_level_building_blocks(nx, nu):
+    """The hand-written single-wave primitives of csrc/wave_la.hpp, each on its own against numpy (fp64, 1e-12 relative): the MFMA block
+    products in the operand layouts the kernels use (plain, transposed, 4-row, diag-scaled, accumulate), the fused product pair of the SLS
+    propagation, the 2-D Gauss-Jordan SPD inverse and the D_k assembly of the block factorisation."""
+    from robust_nonlinear_mpc_amd import _lib
+    import ctypes as C
+    L = _lib.load()
+    rng = np.random.default_rng(nx)
+    MM, NB = nx * nx, nx * nu
+
+    def run(which, ins, n_out):
+        a = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in ins]))
+        out = np.zeros(n_out)
+        rc = L.slsqp_selftest(nx, nu, which, a.ctypes.data_as(C.c_void_p), a.size, out.ctypes.data_as(C.c_void_p), n_out)
+        assert rc == 0, L.slsqp_last_error()
+        return out
+
+    A, Bq, S = rng.normal(size=(nx, nx)), rng.normal(size=(nx, nx)), rng.normal(size=(nx, nx))
+    Bm, K, sc = rng.normal(size=(nx, nu)), rng.normal(size=(nu, nx)), rng.uniform(0.1, 2.0, nx)
+    close = lambda got, want: np.max(np.abs(got - want)) < 1e-12 * max(1.0, np.abs(want).max())
+    assert close(run(0, [A, Bq], MM).reshape(nx, nx), A @ Bq)
+    assert close(run(1, [A, Bq], MM).reshape(nx, nx), A.T @ Bq)
+    assert close(run(2, [Bm, S], NB).reshape(nu, nx), Bm.T @ S)
+    assert close(run(3, [A, Bq, sc], MM).reshape(nx, nx), (A * sc[None, :]) @ Bq)
+    assert close(run(4, [Bm, K, A], MM).reshape(nx, nx), A + Bm @ K)
+    o = run(5, [K, A, Bq], NB + MM)
+    assert close(o[:NB].reshape(nu, nx), K @ Bq) and close(o[NB:].reshape(nx, nx), A @ Bq)
+    # SPD inverse: a matrix conditioned like the D_k of the QPs (entries over a few orders of magnitude), lower triangle given
+    Mx = rng.normal(size=(nx, nx + 3))
+    Y = (Mx @ Mx.T) * np.outer(sc, sc) + 1e-3 * np.eye(nx)
+    o = run(6, [np.tril(Y)], MM + 1)
+    assert o[MM] == 0.0
+    Di = o[:MM].reshape(nx, nx)
+    assert np.array_equal(Di, Di.T)
+    assert np.max(np.abs(Di @ Y - np.eye(nx))) < 1e-15 * np.linalg.cond(Y) * nx
+    assert np.max(np.abs(Di - np.linalg.inv(Y))) < 1e-15 * np.linalg.cond(Y) * nx * np.abs(np.linalg.inv(Y)).max()
+    # a matrix that is not positive definite is reported (pivot clamped, flag set)
+    Yb = Y.copy(); Yb[nx // 2, nx // 2] = -1.0
+    assert run(6, [np.tril(Yb)], MM + 1)[MM] != 0.0
+    # D_k assembly: lower triangle of  M1 A' + B diag(piu) B' - T M1' + diag(d) + delta,  M1 = A diag(pix)
+    T = rng.normal(size=(nx, nx)); pix, piu, d = rng.uniform(0.1, 2.0, nx), rng.uniform(0.1, 2.0, nu), rng.uniform(0.1, 2.0, nx)
+    M1 = A * pix[None, :]
+    want = M1 @ A.T + (Bm * piu[None, :]) @ Bm.T - T @ M1.T + np.diag(d + 1e-13)
+    got = run(7, [A, Bm, T, pix, piu, d], MM).reshape(nx, nx)
+    assert close(np.tril(got), np.tril(want))

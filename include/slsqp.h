@@ -71,7 +71,9 @@ typedef struct {
                             right-hand sides / residuals / KKT certificate in fp64, two more refinement solves per polish; instances
                             that do not certify are solved again in fp64 (BASELINE config 3, "fp32 vs fp64") */
     int as_first;        /* 1 (default): a cold QP solve first runs the active-set iteration from the empty set (round 0 = the equality-constrained
-                            optimum), certificate-checked like every polish, and only falls back to the interior point when that fails */
+                            optimum), certificate-checked like every polish, and only falls back to the interior point when that fails; a failed warm
+                            attempt is followed by that attempt from the empty set too.  2: as 1, but a failed warm attempt goes straight to the
+                            interior point.  0: no active-set attempt before the interior point */
     int as_rounds;       /* correction rounds such an attempt may use (default 24) */
     int as_max_viol;     /* an active-set attempt is abandoned when one of its solves leaves more violated bounds than this (default 64), or more
                             than twice the previous round's + 8: a set that pins both ends of a dynamics row makes the solve blow up */
@@ -79,6 +81,8 @@ typedef struct {
                             fails restart the interior point from a copy of the first QP's iterate at mu ~ 1e-3 |q|inf instead of from scratch */
     int time_kernels;    /* 0 (default): no per-launch timing.  1: HIP event pairs around every launch of the dominant QP kernel on the
                             handle's stream, read with slsqp_kernel_timing (bench.py's roofline leg) */
+    int as_warm_max_set; /* 28 (default): the last QP of a call skips its warm active-set attempt and starts the interior point when the first QP ended
+                            with more active bounds than this (0 = never skip) */
 } slsqp_opts;
 
 void slsqp_default_opts(slsqp_opts *o);

@@ -87,6 +87,9 @@ struct QpArgs {
     int as_rounds;            // rounds such an attempt may take (a warm one: warm_rounds)
     int *diag;                // QP_DIAG_SPAN builds: (B,2,16,2) first / last stage whose set entry changed, per active-set round
     int warm_shift;           // 1: the first QP's warm set is the previous call's set moved one stage towards the start of the horizon (receding horizon)
+    int as_warm_max_set;      // a QP that follows another one of the same call (tightened bounds) skips the warm attempt and goes straight to the
+                              // interior point when the set it would start from has more entries than this (0 = never): from ~30 active bounds a
+                              // tightening moves so many of them that the rounds cost more than the interior point
     int as_max_viol;          // an attempt is abandoned when a solve leaves more violated bounds than this, or more than 2 x the previous round's + 8
     int n_refine;             // refinement solves per polish (1 in fp64, 3 with fp32 factorisations)
     double early_ctol;        // tolerance (relative to max(1,|q|inf)) of the look at the un-refined polish solve: its accuracy class
@@ -565,7 +568,14 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         // when the solve in between did not end on a certificate (e.g. a measured state outside its own box, status 2): ACT1 is only ever
         // written with a certified set
         const bool from_act1 = a.warm && status == ST_INIT && a.stat_slot == 0 && a.snap_use == 0 && stp->act1_ok != 0.0;
-        const bool warm = a.warm && status == ST_INIT && (from_act1 || (((int)stp->status == 0) && ((int)stp->phase == P_DONE)));
+        bool warm = a.warm && status == ST_INIT && (from_act1 || (((int)stp->status == 0) && ((int)stp->phase == P_DONE)));
+        bool big_set = false;
+        if (warm && !from_act1 && a.snap_use != 0 && a.as_warm_max_set > 0) {
+            double cnt = 0.0;
+            for (int e = lane; e < n; e += 64) cnt += (ACT[e] != 0.0) ? 1.0 : 0.0;
+            big_set = wla::wave_sum(cnt) > (double)a.as_warm_max_set;
+            if (big_set) warm = false;
+        }
         const double *prev = a.primal + (size_t)b * n;
         // a later QP of the same call whose previous solve was certified: same A, B, weights, and the scratch still holds the factorisation of
         // exactly the set it starts from -- its first tick needs no factorisation at all
@@ -600,7 +610,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             s0.phase = (status == ST_INIT) ? (warm ? P_POL0 : P_INIT) : P_DONE; s0.it = 0; s0.status = status; s0.mu = 0; s0.smu = 0; s0.qscale = qscale;
             s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1; s0.ticks = 0; s0.fticks = 0; s0.tight = 0; s0.pad = 0;
             s0.snap_call = stp->snap_call; s0.snap_mu = stp->snap_mu; s0.snap_used = 0; s0.pad2 = 0;
-            s0.mode = a.as_first ? 0.0 : 1.0; s0.cold_as = 0; s0.nviol = 0; s0.path = warm ? 10.0 : 0.0;
+            s0.mode = (a.as_first && !big_set) ? 0.0 : 1.0; s0.cold_as = big_set ? 1.0 : 0.0; s0.nviol = 0; s0.path = warm ? 10.0 : (big_set ? 1.0 : 0.0);
             s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.uf_valid = 0; s0.res_only = 0; s0.tbox = 0; s0.pad3 = 0; s0.pad4 = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
@@ -1013,7 +1023,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         // an active-set attempt is abandoned.  A warm one is followed by the attempt from the empty set (when enabled and not yet made), then
         // the interior point takes over: from the iterate an earlier QP of this call left behind when there is one (no P_INIT solve then),
         // from its cold start otherwise
-        const bool try_cold_as = a.as_first && s.cold_as == 0.0 && s.warm == 1.0;
+        const bool try_cold_as = a.as_first == 1 && s.cold_as == 0.0 && s.warm == 1.0;   // (as_first 2: a failed warm attempt goes straight to the interior point)
         s.pol_round = 0.0; s.pol_fail = 0.0; s.seth[0] = s.seth[1] = s.seth[2] = s.seth[3] = 0ULL; s.uf_valid = 0.0;
         if (!try_cold_as && a.snap_use && s.snap_call == a.call_id && a.call_id != 0.0) {
             s.warm = -1.0; s.path = (s.path >= 10.0 ? 10.0 : 0.0) + 2.0;

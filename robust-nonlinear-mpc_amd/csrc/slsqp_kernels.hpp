@@ -473,6 +473,15 @@ __device__ __forceinline__ Elem elem_of(int e, int n, int N, const double *ub, c
 enum { P_INIT = 0, P_PRED = 1, P_CORR = 2, P_POL0 = 3, P_POL1 = 4, P_POL2 = 5, P_DONE = 6 };
 // equality residual (relative to max(1,|q|inf)) below which an un-refined active-set solve is accepted without the refinement solve (the certificate
 // itself asks for 1e-6; a solve that misses this tighter bound is refined as before)
+#ifndef STALL_WINDOW
+#define STALL_WINDOW 6
+#endif
+#ifndef STALL_MIN_IT
+#define STALL_MIN_IT 24
+#endif
+#ifndef STALL_FACTOR
+#define STALL_FACTOR 0.5
+#endif
 #ifndef AS_DELTA
 #define AS_DELTA 1e-13      // diagonal regularisation of the active-set rounds' factorisations
 #endif
@@ -490,9 +499,10 @@ struct QpState {   // per instance, 40 doubles
                                                   // fact_call: call whose last certified solve left its factorisation (for the set in ACT) in the
                                                   // scratch; act1_ok: ACT1 holds a certified set; uf_valid: the last forward sweep solved the current attempt's
                                                   // un-refined system, so UF's leading u_k carry over to the next round (ne_forward ks)
-    double res_only, tbox, pad3, pad4;            // res_only 1: the look at the un-refined solve already found stationarity, box and multiplier signs within the
+    double res_only, tbox, stall_ref, stall_it;            // res_only 1: the look at the un-refined solve already found stationarity, box and multiplier signs within the
                                                   // certificate's tolerance (tbox: its box violation); the tick that follows only has to measure the equality
-                                                  // residual -- if that is small too the un-refined solve IS the certified answer and the refinement is skipped
+                                                  // residual -- if that is small too the un-refined solve IS the certified answer and the refinement is skipped;
+                                                  // stall_ref / stall_it: max(residual, mu) of the interior point at its last checkpoint (every 6 iterations)
 };
 static_assert(sizeof(QpState) == 40 * sizeof(double), "QpState size");
 
@@ -611,7 +621,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1; s0.ticks = 0; s0.fticks = 0; s0.tight = 0; s0.pad = 0;
             s0.snap_call = stp->snap_call; s0.snap_mu = stp->snap_mu; s0.snap_used = 0; s0.pad2 = 0;
             s0.mode = (a.as_first && !big_set) ? 0.0 : 1.0; s0.cold_as = big_set ? 1.0 : 0.0; s0.nviol = 0; s0.path = warm ? 10.0 : (big_set ? 1.0 : 0.0);
-            s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.uf_valid = 0; s0.res_only = 0; s0.tbox = 0; s0.pad3 = 0; s0.pad4 = 0;
+            s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.uf_valid = 0; s0.res_only = 0; s0.tbox = 0; s0.stall_ref = 0; s0.stall_it = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
 #ifdef QP_DIAG_SPAN
@@ -1072,6 +1082,18 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             for (int o = lane; o < N * NX; o += 64) SNUA[o] = NUA[o];
             s.pad2 = 1.0; s.snap_call = a.call_id; s.snap_mu = mu;
         }
+        // An interior point that no longer makes progress is at an infeasible (or hopelessly ill-posed) QP: once the usual iteration count (7-13) is
+        // well behind it (24 iterations), max(residual, mu) must at least halve over six iterations, else the solve is flagged like one that ran out of iterations
+        // (status 1) -- 24-30 instead of max_iter = 60 iterations for the stragglers that would otherwise hold the whole launch.
+        bool stalled = false;
+        {
+            const double phi = fmax(res, mu);
+            if (s.stall_ref == 0.0) { s.stall_ref = phi; s.stall_it = (double)it; }
+            else if ((double)it - s.stall_it >= (double)STALL_WINDOW) {
+                stalled = it >= STALL_MIN_IT && phi > STALL_FACTOR * s.stall_ref;
+                s.stall_ref = phi; s.stall_it = (double)it;
+            }
+        }
         if (!(res == res) || !(mu == mu) || res > 1e30) { status = 3; phase = P_DONE; }
         else if (res < tol && mu < tol) {
             status = 4;
@@ -1087,7 +1109,10 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 ACT[e] = aU ? 1.0 : (aL ? -1.0 : 0.0); PI[e] = pi; V[e] = (pi != 0.0) ? -pi * el.q : z0;
             }
             phase = P_POL0; s.kmin = 0.0; s.uf_valid = 0.0;
-        } else if (it >= a.max_iter) { status = 1; phase = P_DONE; }
+        } else if (it >= a.max_iter || stalled) {
+            // (a solve that had reached the interior-point tolerance and was resumed towards 1e-9 keeps its interior-point-accurate answer)
+            status = (s.tight != 0.0 && status == 4) ? 4 : 1; phase = P_DONE;
+        }
         else phase = P_PRED;
     }
 

@@ -1,0 +1,25 @@
+"""Long closed loop in the hard regime: which QP solves are the stragglers of a launch (ticks, interior-point iterations, final status)?"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
+m = get_model("rocket")
+B, N, steps = 1024, 20, int(sys.argv[2]) if len(sys.argv) > 2 else 30
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+x0 = m.x_ref + scale * (m.extra["x0"] - m.x_ref)
+W = np.stack([disturbance_stream(s, steps, m.nx) for s in range(B)], axis=1)
+cl = ClosedLoopMPC(m, N, B)
+cl.reset(np.tile(x0, (B, 1)), solve_nominal=True, continuation=2 if scale > 0.6 else 1)
+for i in range(steps):
+    cl.step(W[i], fetch=False)
+    qs = cl.f.get("qp_stats", (2, 8), np.int32)
+    line = f"step {i:2d}:"
+    for slot in (0, 1):
+        st, tk, its = qs[:, slot, 6], qs[:, slot, 1], qs[:, slot, 0]
+        ran = (st != -1) & (st != 2)
+        big = ran & (tk > 40)
+        line += (f" | QP{slot+1} ran {ran.mean():.2f} status(0,1,3,4) {[(st[ran] == v).sum() for v in (0, 1, 3, 4)]} ticks mean {tk[ran].mean() if ran.any() else 0:.1f} max {tk.max()}"
+                 f" >40 ticks: {big.sum()} (status {np.bincount(st[big], minlength=5).tolist() if big.any() else []}, its max {its[big].max() if big.any() else 0})")
+    print(line, flush=True)
+cl.close()

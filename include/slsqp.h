@@ -70,10 +70,11 @@ typedef struct {
     int precision;       /* 0 (default): fp64 throughout.  1: mixed -- block factorisations, stored inverses and substitutions in fp32,
                             right-hand sides / residuals / KKT certificate in fp64, two more refinement solves per polish; instances
                             that do not certify are solved again in fp64 (BASELINE config 3, "fp32 vs fp64") */
-    int as_first;        /* 1 (default): a cold QP solve first runs the active-set iteration from the empty set (round 0 = the equality-constrained
+    int as_first;        /* 1: a cold QP solve first runs the active-set iteration from the empty set (round 0 = the equality-constrained
                             optimum), certificate-checked like every polish, and only falls back to the interior point when that fails; a failed warm
-                            attempt is followed by that attempt from the empty set too.  2: as 1, but a failed warm attempt goes straight to the
-                            interior point.  0: no active-set attempt before the interior point */
+                            attempt is followed by that attempt from the empty set too.  2 (default): as 1, but a failed warm attempt goes straight to
+                            the interior point (the retry from the empty set rescued 0.08 % of the failed warm attempts where it was measured).
+                            0: no active-set attempt before the interior point */
     int as_rounds;       /* correction rounds such an attempt may use (default 24) */
     int as_max_viol;     /* an active-set attempt is abandoned when one of its solves leaves more violated bounds than this (default 64), or more
                             than twice the previous round's + 8: a set that pins both ends of a dynamics row makes the solve blow up */

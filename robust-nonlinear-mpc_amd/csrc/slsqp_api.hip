@@ -32,7 +32,7 @@ extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
     o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-6; o->conv_tol = 1e-3;
     o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 20;
-    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0; o->as_first = 1; o->as_rounds = 24; o->as_max_viol = 64; o->ipm_restart = 1; o->as_warm_max_set = 28;
+    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0; o->as_first = 2; o->as_rounds = 24; o->as_max_viol = 64; o->ipm_restart = 1; o->as_warm_max_set = 28;
 }
 
 struct slsqp_handle {

@@ -420,6 +420,8 @@ def main():
             # the CPU gets the instances whose two QPs the GPU solved in that step (steps flagged infeasible at x0 cost neither side any work)
             qs0 = f0.get("qp_stats", (2, 8), np.int32)
             sel = np.flatnonzero((qs0[:, 0, 6] == 0) & (qs0[:, 1, 6] == 0))[:1024]
+            if sel.size < 64:      # (a step in which hardly any instance was solved: take the first instances as they are)
+                sel = np.arange(min(f0.B, 1024))
             cpu_data = {k: f0.get(k, shp)[sel] for k, shp in (("A", (N, m.nx, m.nx)), ("Bm", (N, m.nx, m.nu)), ("c", (N, m.nx)), ("g", (N, m.ni)), ("gN", (m.ni_f,)),
                                                                ("q", (n_var,)), ("x0_arg", (m.nx,)))}
         elif args.workload == "synthetic" and not args.no_cpu and world == 1:

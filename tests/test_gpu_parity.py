@@ -832,3 +832,35 @@ def test_wave_level_building_blocks(nx, nu):
     want = M1 @ A.T + (Bm * piu[None, :]) @ Bm.T - T @ M1.T + np.diag(d + 1e-13)
     got = run(7, [A, Bm, T, pix, piu, d], MM).reshape(nx, nx)
     assert close(np.tril(got), np.tril(want))
+
+
+def test_infeasible_box_is_flagged_early_by_the_stagnation_rule():
+    """A QP whose x_0 is fine but whose box is empty at one stage (upper bound below the lower one) has no solution: the interior point must end
+    flagged (status 1 or 3, never 0 / 4) after a few dozen iterations instead of qp_max_iter = 60, and its neighbours in the batch are untouched."""
+    from robust_nonlinear_mpc_amd import BatchedFastSLS, make_batch
+    B = 8
+    batch = make_batch("quadrotor", os.path.join(GOLDEN, "sweep_quadrotor_N20_s0.npz"), B, seed=5)
+    m, N = batch["model"], batch["N"]
+    f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, batch=B)
+    f.update_dynamics_list(batch["A"], batch["B"], batch["E"], batch["g"], batch["gN"], batch["c"])
+    f.update_linear_cost(batch["q"])
+    x0 = batch["x0_arg"]
+    ub, lb = f.get("ubg", (f.mb,)), f.get("lbg", (f.mb,))
+    l = np.concatenate([lb, -x0 - 1e-10], axis=1); u = np.concatenate([ub, -x0 + 1e-10], axis=1)
+    f.opts.warm_start = 0
+    f.qp_update_data_vec(batch["q"], l, u)
+    xr, yr, st, it, _ = f.qp_solve()
+    assert (st == 0).all()
+    # instance 2: stage 5, state component 1:  z <= hi  and  -z <= -(hi + 0.5)  cannot both hold
+    SR, nz = m.nx + m.ni, m.nx + m.nu
+    u2 = u.copy()
+    row_hi, row_lo = 5 * SR + m.nx + 1, 5 * SR + m.nx + nz + 1
+    u2[2, row_lo] = -(u2[2, row_hi] + 0.5)
+    f.qp_update_data_vec(batch["q"], l, u2)
+    x, y, st, it, _ = f.qp_solve()
+    qs = f.get("qp_stats", (2, 8), np.int32)
+    f.close()
+    assert st[2] in (1, 3) and it[2] < 45, (st[2], it[2])
+    assert qs[2, 0, 1] < 110
+    ok = [b for b in range(B) if b != 2]
+    assert (st[ok] == 0).all() and np.array_equal(x[ok], xr[ok])

@@ -50,7 +50,8 @@ struct slsqp_handle {
     int *status, *iters, *itnum, *has_prev, *conv, *alive, *mask, *success, *infeas, *counter;
     int *scp_active, *scp_success, *scp_iters, *pending_reset, *scp_upd; double *scp_dmax;
     int horizon_shifted = 0;
-    bool solve_timing_pending = false, pend_first = false; double pend_qp = 0, pend_sw = 0;
+    // timeline: event pairs recorded on the stream with a role (0 QP, 1 sweep, 2 whole solve, 3 linearisation); read after a synchronisation
+    std::vector<hipEvent_t> tl; std::vector<int> tl_role; int tl_n = 0; double tl_acc[4] = {0, 0, 0, 0};
     int *qp_diag = nullptr;     // QP_DIAG_SPAN builds only
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
     int *retry; int mx_retry, mx_retry_total;
@@ -164,6 +165,8 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { free_all(h->owned); hipStreamDestroy(h->st); delete h; return nullptr; }
     for (auto &e : h->ev) hipEventCreate(&e);
+    h->tl.resize(2 * 256); for (auto &e : h->tl) hipEventCreate(&e);
+    h->tl_role.assign(256, 0); h->tl_n = 0;
     h->kev.resize(2 * 256); for (auto &e : h->kev) hipEventCreate(&e);
     h->n_kev = 0; h->t_fwd = 0; h->n_fwd = 0; h->fwd_inst = 0; h->time_kernels = false; h->call_id = 0;
     // CSC offsets of the reference's frozen pattern (qp_jit.py:101-123,178-186; columns sorted by row)
@@ -221,6 +224,7 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     free_all(h->owned);
     if (h->stage) hipFree(h->stage);
     for (auto &e : h->ev) hipEventDestroy(e);
+    for (auto &e : h->tl) hipEventDestroy(e);
     for (auto &e : h->kev) hipEventDestroy(e);
     hipStreamDestroy(h->st);
     delete h;
@@ -509,18 +513,28 @@ static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, cons
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
 
 // `active` (device, B ints or NULL = all): instances that take part in this call; the others keep every result array untouched.
-// timing of a solve whose launches have completed (the stream has been synchronised since): sums the event pairs solve_impl left behind
-static void finish_solve_timing(slsqp_handle *h) {
-    if (!h->solve_timing_pending) return;
+// ---- timeline of a solve / closed-loop step: event pairs with a role, summed once the stream has been synchronised ----
+static int tl_begin(slsqp_handle *h, int role) {
+    if (h->tl_n >= (int)h->tl_role.size()) return -1;          // full: this interval goes untimed (flush points keep that from happening)
+    const int i = h->tl_n++;
+    h->tl_role[i] = role;
+    hipEventRecord(h->tl[2 * i], h->st);
+    return i;
+}
+static void tl_end(slsqp_handle *h, int i) { if (i >= 0) hipEventRecord(h->tl[2 * i + 1], h->st); }
+// only right after a stream synchronisation: add the recorded intervals to the accumulators, recycle the events
+static void tl_flush(slsqp_handle *h) {
+    for (int i = 0; i < h->tl_n; i++) { float ms = 0; if (hipEventElapsedTime(&ms, h->tl[2 * i], h->tl[2 * i + 1]) == hipSuccess) h->tl_acc[h->tl_role[i]] += ms; }
+    h->tl_n = 0;
     harvest_kernel_events(h);
-    double acc_qp = h->pend_qp, acc_sw = h->pend_sw;
-    if (h->pend_first) { acc_qp += ev_ms(h->ev[1], h->ev[2]); acc_sw += ev_ms(h->ev[3], h->ev[4]); }
-    acc_qp += ev_ms(h->ev[8], h->ev[9]);
-    h->t_total = ev_ms(h->ev[0], h->ev[5]); h->t_qp = acc_qp; h->t_sweep = acc_sw;
-    h->solve_timing_pending = false;
+}
+static void tl_take(slsqp_handle *h) {     // accumulators -> the handle's timing fields (what slsqp_last_timing reports)
+    tl_flush(h);
+    h->t_qp = h->tl_acc[0]; h->t_sweep = h->tl_acc[1]; h->t_total = h->tl_acc[2]; h->t_jac = h->tl_acc[3];
+    h->tl_acc[0] = h->tl_acc[1] = h->tl_acc[2] = h->tl_acc[3] = 0;
 }
 
-// no_sync: return with the launches queued (the caller synchronises the stream later and then calls finish_solve_timing)
+// no_sync: return with the launches queued (the caller synchronises the stream later and then calls tl_take)
 static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts, const int *active, bool no_sync = false) {
     hipSetDevice(h->dev);
     if (h->general_G) return fail("general G: only the sweep-level boundary (slsqp_sweep) is available; the QP solver needs box constraints G = [I;-I]");
@@ -543,7 +557,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     h->call_id += 1.0;
     // the caller moved the horizon one stage on since the last solve (slsqp_cl_step's reset_warm_start): the first QP's warm set moves with it
     const int wshift = h->horizon_shifted; h->horizon_shifted = 0;
-    HIPCHK(hipEventRecord(h->ev[0], h->st));
+    const int tl_tot = tl_begin(h, 2);
     if (active) hipLaunchKernelGGL(k_copy_int, dim3(gb), dim3(256), 0, h->st, active, h->alive, B);
     else hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->alive, 1, B);
     hipLaunchKernelGGL(k_apply_pending_reset, dim3(B), dim3(256), 0, h->st, B, h->pending_reset, active, h->itnum, h->eta, (size_t)d.N * d.N * d.ni, h->eta_f,
@@ -563,12 +577,10 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         } else hipLaunchKernelGGL(k_init_backoff, dim3(B), dim3(256), 0, h->st, ia);
         h->beta_inited = true;
     }
-    double acc_qp = 0, acc_sw = 0;
-    bool deferred = false;
     for (int i = 0; i < steps; i++) {
-        HIPCHK(hipEventRecord(h->ev[1], h->st));
+        const int tl_q = tl_begin(h, 0);
         if (launch_qp(h, h->alive, &o, (i > 0 || o.warm_start) ? 1 : 0, nullptr, 0, 1, i > 0 ? 1 : 0, i == 0 ? wshift : 0)) return -1;
-        HIPCHK(hipEventRecord(h->ev[2], h->st));
+        tl_end(h, tl_q);
         hipLaunchKernelGGL(k_post_qp, dim3(gb), dim3(256), 0, h->st, B, h->status, h->alive, h->infeas);
         EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff, h->stale, (i == 0 && sweep_shared_allowed()) ? 1 : 0};
         hipLaunchKernelGGL(k_eta, dim3(B), dim3(256), 0, h->st, ea);
@@ -577,36 +589,33 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), h->st));
         hipLaunchKernelGGL(k_post_conv, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->conv, h->alive, h->mask, h->success, h->itnum, h->counter, h->stale);
         if (i == 0) hipLaunchKernelGGL(k_fix_beta, dim3(B), dim3(256), 0, h->st, d.N, d.ni, d.ni_f, o.eps_backoff, active, h->mask, h->stale, h->beta, h->beta_f);
-        HIPCHK(hipEventRecord(h->ev[3], h->st));
+        const int tl_s = tl_begin(h, 1);
         if (launch_sweep(h, h->mask, h->eta, h->eta_f, o.eps_backoff, /* beta == eps for every column right after initialize_backoff */ i == 0)) return -1;
-        HIPCHK(hipEventRecord(h->ev[4], h->st));
+        tl_end(h, tl_s);
         TightenArgs ta{B, d.N, d.nx, d.nu, d.ni, d.ni_f, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1, h->ct_part, h->cost_tube};
         hipLaunchKernelGGL(k_tighten, dim3(B), dim3(128), 0, h->st, ta);
-        if (rti && steps == 1) { deferred = true; continue; }   // the script setting of the rocket: nothing to decide on the host, the stream runs on into the final QP
+        if (rti) continue;      // RTI mode (every closed-loop script): nothing to decide on the host, the stream runs on
         int nmask = 0;
         HIPCHK(hipMemcpyAsync(&nmask, h->counter, sizeof(int), hipMemcpyDeviceToHost, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
-        harvest_kernel_events(h);
-        acc_qp += ev_ms(h->ev[1], h->ev[2]); acc_sw += ev_ms(h->ev[3], h->ev[4]);
-        if (!rti && nmask == 0) break;   // every instance converged or failed
+        if (nmask == 0) break;   // every instance converged or failed
     }
     // final QP: RTI always (fast_SLS_jit.py:293); converge mode only for instances that hit MAX_ITER (:311)
-    HIPCHK(hipEventRecord(h->ev[8], h->st));
+    const int tl_q2 = tl_begin(h, 0);
     if (launch_qp(h, h->alive, &o, 1, nullptr, 1, 1, 1)) return -1;
-    HIPCHK(hipEventRecord(h->ev[9], h->st));
+    tl_end(h, tl_q2);
     hipLaunchKernelGGL(k_finish, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->alive, h->infeas, h->success, active, h->pending_reset);
-    HIPCHK(hipEventRecord(h->ev[5], h->st));
-    h->solve_timing_pending = true; h->pend_qp = acc_qp; h->pend_sw = acc_sw; h->pend_first = deferred;
+    tl_end(h, tl_tot);
     if (no_sync) return 0;
     HIPCHK(hipStreamSynchronize(h->st));
-    finish_solve_timing(h);
+    tl_take(h);
     return 0;
 }
 
 extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts) { return solve_impl(h, x0, loc, opts, nullptr); }
 
 extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms5) {
-    if (h->solve_timing_pending) { hipSetDevice(h->dev); hipStreamSynchronize(h->st); finish_solve_timing(h); }
+    if (h->tl_n > 0) { hipSetDevice(h->dev); hipStreamSynchronize(h->st); tl_take(h); }
     ms5[0] = h->t_total; ms5[1] = h->t_qp; ms5[2] = h->t_sweep; ms5[3] = h->t_total - h->t_qp - h->t_sweep; ms5[4] = h->t_jac;
     return 0;
 }
@@ -616,7 +625,7 @@ extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out8) {
     hipMemcpyAsync(il, h->inst_launches, sizeof(il), hipMemcpyDeviceToHost, h->st);
     hipMemsetAsync(h->inst_launches, 0, sizeof(il), h->st);
     hipStreamSynchronize(h->st);
-    finish_solve_timing(h);
+    if (h->tl_n > 0) tl_take(h); else harvest_kernel_events(h);
     out8[0] = h->t_fwd; out8[1] = (double)h->n_fwd; out8[2] = (double)h->mx_retry_total; out8[3] = (double)il[0]; out8[4] = (double)il[1];
     out8[5] = (double)il[2]; out8[6] = (double)il[3]; out8[7] = (double)il[4];
     h->t_fwd = 0; h->n_fwd = 0; h->mx_retry_total = 0;
@@ -862,7 +871,6 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
         if (slsqp_reset(h)) return -1;
         h->horizon_shifted = 1;
     }
-    double tq = 0, ts = 0, tt = 0;
     slsqp_opts o;
     if (opts) o = *opts; else slsqp_default_opts(&o);
     // SCP_SLS.solve (solver/SCP_SLS_jit.py:65-152): rti > 0 -> exactly rti iterations; rti <= 0 -> until |delta|inf < scp_eps
@@ -874,11 +882,11 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
     hipLaunchKernelGGL(k_fill_int, dim3(gbi), dim3(256), 0, h->st, h->scp_active, 1, B);
     hipLaunchKernelGGL(k_fill_int, dim3(gbi), dim3(256), 0, h->st, h->scp_success, 0, B);
     hipLaunchKernelGGL(k_fill_int, dim3(gbi), dim3(256), 0, h->st, h->scp_iters, 0, B);
-    double tj = 0;
-    bool timing_done = false;
-    HIPCHK(hipEventRecord(h->ev[6], h->st));
-    if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, nullptr)) return -1;
-    HIPCHK(hipEventRecord(h->ev[7], h->st));
+    {
+        const int tl_j = tl_begin(h, 3);
+        if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, nullptr)) return -1;
+        tl_end(h, tl_j);
+    }
     for (int ii = 0; ii < max_it; ii++) {
         hipLaunchKernelGGL(k_cl_x0arg, dim3(64), dim3(256), 0, h->st, a);
         if (solve_impl(h, h->x0arg, SLSQP_DEVICE, &o, h->scp_active, /* no_sync */ true)) return -1;
@@ -888,16 +896,18 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
         if (h->model_id == 0) hipLaunchKernelGGL((k_cl_infeas<0>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
         else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_infeas<1>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
         else hipLaunchKernelGGL((k_cl_infeas<2>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
-        if (ii + 1 == max_it) break;        // (the last iteration's timing is collected after the step's final synchronisation)
-        int nact = 0;
-        HIPCHK(hipMemcpyAsync(&nact, h->counter + 2, sizeof(int), hipMemcpyDeviceToHost, h->st));
-        HIPCHK(hipStreamSynchronize(h->st));
-        finish_solve_timing(h);
-        tq += h->t_qp; ts += h->t_sweep; tt += h->t_total; tj += ev_ms(h->ev[6], h->ev[7]);
-        if (nact == 0) { timing_done = true; break; }
-        HIPCHK(hipEventRecord(h->ev[6], h->st));
+        if (ii + 1 == max_it) break;
+        if (converge) {     // the host decides whether anyone is still iterating; RTI mode runs its rti iterations without looking (the instances that
+                            // failed are masked on the device), so a whole RTI step is one burst of launches on the stream
+            int nact = 0;
+            HIPCHK(hipMemcpyAsync(&nact, h->counter + 2, sizeof(int), hipMemcpyDeviceToHost, h->st));
+            HIPCHK(hipStreamSynchronize(h->st));
+            tl_flush(h);
+            if (nact == 0) break;
+        }
+        const int tl_j = tl_begin(h, 3);
         if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, h->scp_active)) return -1;   // update_jacobian for the next iteration (:138)
-        HIPCHK(hipEventRecord(h->ev[7], h->st));
+        tl_end(h, tl_j);
     }
     if (h->log_steps > 0 && h->cl_steps < h->log_steps) {
         ClLogArgs la{h->B, d.N, d.nx, d.nu, h->log_steps, h->cl_steps, h->Xn, h->Un, h->backoff_x, h->backoff_u, h->scp_success, h->scp_iters,
@@ -909,8 +919,7 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
     else hipLaunchKernelGGL((k_cl_shift_plant<2>), dim3(gb), dim3(64), 0, h->st, a, 0, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->st));
-    if (!timing_done) { finish_solve_timing(h); tq += h->t_qp; ts += h->t_sweep; tt += h->t_total; tj += ev_ms(h->ev[6], h->ev[7]); }
-    h->t_qp = tq; h->t_sweep = ts; h->t_total = tt; h->t_jac = tj;
+    tl_take(h);
     h->cl_steps++;
     return 0;
 }

@@ -357,6 +357,112 @@ __global__ void k_apply_pending_reset(int B, int *pending, const int *active, in
     __syncthreads();
     if (threadIdx.x == 0) { itnum[b] = 0; pending[b] = 0; stale[b] &= ~16; }
 }
+// The elementwise work between the first QP of a fast-SLS iteration and its sweep in ONE launch (one workgroup per instance), in the order of the
+// five launches it replaces: k_post_qp (a failed QP drops the instance), k_eta (evaluate_dual_eta), k_conv (check_convergence_socp), k_post_conv
+// (mask of the instances that go on to the sweep) and, in the first iteration, k_fix_beta.  A pendulum closed-loop step is launch-bound: 30 of its
+// ~120 launches were these.
+struct AfterQpArgs {
+    int B, rti, first_iter;
+    const int *status, *active;
+    int *alive, *infeas, *mask, *success, *itnum, *counter, *stale, *conv;
+    EtaArgs ea; ConvArgs ca;
+    double *beta_w, *beta_f_w;     // the same arrays as ea.beta / ea.beta_f, writable (k_fix_beta's part)
+};
+__global__ __launch_bounds__(256) void k_after_qp(AfterQpArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_alive, s_m, s_stale;
+    if (tid == 0) {
+        int al = a.alive[b];
+        if (al) { const int st = a.status[b]; if (!(st == 0 || st == 4)) { al = 0; a.alive[b] = 0; a.infeas[b] = 1; } }
+        s_alive = al;
+    }
+    __syncthreads();
+    const int alive = s_alive;
+    if (alive) {       // ---- k_eta
+        const EtaArgs &e = a.ea;
+        const int SR = e.NX + e.NI, mb = e.N * SR + e.NIF;
+        const double *du = e.dual + (size_t)b * mb;
+        double *et = e.eta + (size_t)b * e.N * e.N * e.NI, *ef = e.eta_f + (size_t)b * (e.N + 1) * e.NIF;
+        if (e.first_iter) {
+            const double s0 = 2.0 * sqrt(e.eps);
+            for (int o = tid; o < e.N * e.NI; o += blockDim.x) { const int i = o % e.NI, k = o / e.NI; et[((size_t)k * e.N) * e.NI + i] = du[k * SR + e.NX + i] / s0; }
+            for (int o = tid; o < e.NIF; o += blockDim.x) ef[o] = du[e.N * SR + o] / s0;
+        } else {
+            const double *be = e.beta + (size_t)b * e.N * e.N * e.NI, *bf = e.beta_f + (size_t)b * (e.N + 1) * e.NIF;
+            for (int o = tid; o < e.N * e.N * e.NI; o += blockDim.x) {
+                const int i = o % e.NI, j = (o / e.NI) % e.N, k = o / (e.NI * e.N);
+                if (j <= k) et[o] = du[k * SR + e.NX + i] / (2.0 * sqrt(fmax(be[o], e.eps)));
+            }
+            for (int o = tid; o < (e.N + 1) * e.NIF; o += blockDim.x) ef[o] = du[e.N * SR + (o % e.NIF)] / (2.0 * sqrt(fmax(bf[o], e.eps)));
+        }
+    }
+    int cv = 0;
+    if (tid < 64) {    // ---- k_conv (first wave)
+        const ConvArgs &c = a.ca;
+        if (alive) {
+            const double *p = c.primal + (size_t)b * c.n;
+            double *q = c.prev + (size_t)b * c.n;
+            double d = 0.0;
+            for (int o = tid; o < c.n; o += 64) { d = fmax(d, fabs(p[o] - q[o])); q[o] = p[o]; }
+            d = wla::wave_max(d);
+            if (tid == 0) { cv = (c.has_prev[b] && d <= c.tol) ? 1 : 0; c.has_prev[b] = 1; }
+        }
+        if (tid == 0) {
+            a.conv[b] = cv;
+            int st = a.stale[b];
+            if (alive) st = a.ea.first_iter ? ((st & ~1) | 16) : (st & ~(1 | 16));      // what k_eta recorded about the eta array
+            int m = 0;                                                                    // ---- k_post_conv
+            if (alive) {
+                if (cv) { a.success[b] = 1; if (!a.rti) a.alive[b] = 0; }
+                else m = 1;
+            }
+            a.mask[b] = m;
+            if (m) { a.itnum[b] += 1; st = (st & ~(2 | 32)) | 8; if (!a.rti) atomicAdd(a.counter, 1); }
+            s_m = m; s_stale = st;
+            a.stale[b] = st;
+        }
+    }
+    __syncthreads();
+    if (a.first_iter && !((a.active && !a.active[b]) || s_m || !(s_stale & 8))) {      // ---- k_fix_beta
+        const EtaArgs &e = a.ea;
+        double *be = a.beta_w + (size_t)b * e.N * e.N * e.NI, *bf = a.beta_f_w + (size_t)b * (e.N + 1) * e.NIF;
+        for (int o = tid; o < e.N * e.N * e.NI; o += blockDim.x) be[o] = e.eps;
+        for (int o = tid; o < (e.N + 1) * e.NIF; o += blockDim.x) bf[o] = e.eps;
+        if (tid == 0) a.stale[b] = s_stale & ~8;
+    }
+}
+
+// The start of a fast-SLS solve in one launch (one workgroup per instance): x_0 pin value, alive mask, the pending solver reset of an instance
+// whose last converge-mode solve failed, cleared flags, initialize_backoff.  Replaces seven launches.
+struct SolveBeginArgs {
+    int B, NX;
+    const double *x0;            // (B,NX) device, or NULL when the pin value has already been written
+    double *x0val;
+    const int *active; int *alive, *infeas, *success, *pending, *itnum, *stale;
+    double *eta, *eta_f; size_t neta, netaf;
+    InitBackoffArgs ib;          // run = the instances whose back-offs are reset
+};
+__global__ __launch_bounds__(256) void k_solve_begin(SolveBeginArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int act = a.active ? a.active[b] : 1;
+    if (a.x0 && tid < a.NX) a.x0val[(size_t)b * a.NX + tid] = -a.x0[(size_t)b * a.NX + tid];
+    if (tid == 0) { a.alive[b] = act; a.infeas[b] = 0; a.success[b] = 0; }
+    if (a.pending[b] && act) {       // _finish_failure of the previous call (see k_apply_pending_reset)
+        for (size_t o = tid; o < a.neta; o += blockDim.x) a.eta[(size_t)b * a.neta + o] = 0.0;
+        for (size_t o = tid; o < a.netaf; o += blockDim.x) a.eta_f[(size_t)b * a.netaf + o] = 0.0;
+        __syncthreads();
+        if (tid == 0) { a.itnum[b] = 0; a.pending[b] = 0; a.stale[b] &= ~16; }
+    }
+    const InitBackoffArgs &i = a.ib;
+    if (i.run && !i.run[b]) return;
+    const int NZ = i.NX + i.NU, NI = 2 * NZ, NIF = 2 * i.NX, N = i.N;
+    const double sq = sqrt(i.eps);
+    for (int o = tid; o < N * NI; o += blockDim.x) i.backoff[(size_t)b * N * NI + o] = N * sq;
+    for (int o = tid; o < NIF; o += blockDim.x) i.backoff_f[(size_t)b * NIF + o] = (N + 1) * sq;
+    for (int o = tid; o < (N + 1) * i.NX; o += blockDim.x) i.backoff_x[(size_t)b * (N + 1) * i.NX + o] = 0.0;
+    for (int o = tid; o < N * i.NU; o += blockDim.x) i.backoff_u[(size_t)b * N * i.NU + o] = 0.0;
+}
+
 __global__ void k_reset_stale(int *p, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = (p[i] & 8) | 3; }   // eta, K: zero on demand; beta keeps its state
 __global__ void k_and_int(int *p, int v, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] &= v; }
 // instances whose `bit` is set in stale[]: zero their slice of arr1 (and arr2), then clear the bit (last use decides: clear_bit)
@@ -549,7 +655,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         for (size_t i = 0; i < neg.size(); i++) neg[i] = -x0[i];
         HIPCHK(hipMemcpyAsync(h->x0val, neg.data(), neg.size() * sizeof(double), hipMemcpyHostToDevice, h->st));
         HIPCHK(hipStreamSynchronize(h->st));
-    } else {
+    } else if (!h->beta_inited) {
         hipLaunchKernelGGL(k_negate, dim3((B * d.nx + 255) / 256), dim3(256), 0, h->st, x0, h->x0val, B * d.nx);
     }
     const bool rti = o.rti_steps > 0;
@@ -558,6 +664,12 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     // the caller moved the horizon one stage on since the last solve (slsqp_cl_step's reset_warm_start): the first QP's warm set moves with it
     const int wshift = h->horizon_shifted; h->horizon_shifted = 0;
     const int tl_tot = tl_begin(h, 2);
+    if (h->beta_inited) {     // every solve but the handle's first: the whole preamble in one launch
+        SolveBeginArgs sb{B, d.nx, loc == SLSQP_HOST ? nullptr : x0, h->x0val, active, h->alive, h->infeas, h->success, h->pending_reset, h->itnum, h->stale,
+                          h->eta, h->eta_f, (size_t)d.N * d.N * d.ni, (size_t)(d.N + 1) * d.ni_f,
+                          InitBackoffArgs{B, d.N, d.nx, d.nu, o.eps_backoff, active, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, 0}};
+        hipLaunchKernelGGL(k_solve_begin, dim3(B), dim3(256), 0, h->st, sb);
+    } else {
     if (active) hipLaunchKernelGGL(k_copy_int, dim3(gb), dim3(256), 0, h->st, active, h->alive, B);
     else hipLaunchKernelGGL(k_fill_int, dim3(gb), dim3(256), 0, h->st, h->alive, 1, B);
     hipLaunchKernelGGL(k_apply_pending_reset, dim3(B), dim3(256), 0, h->st, B, h->pending_reset, active, h->itnum, h->eta, (size_t)d.N * d.N * d.ni, h->eta_f,
@@ -577,18 +689,17 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         } else hipLaunchKernelGGL(k_init_backoff, dim3(B), dim3(256), 0, h->st, ia);
         h->beta_inited = true;
     }
+    }
     for (int i = 0; i < steps; i++) {
         const int tl_q = tl_begin(h, 0);
         if (launch_qp(h, h->alive, &o, (i > 0 || o.warm_start) ? 1 : 0, nullptr, 0, 1, i > 0 ? 1 : 0, i == 0 ? wshift : 0)) return -1;
         tl_end(h, tl_q);
-        hipLaunchKernelGGL(k_post_qp, dim3(gb), dim3(256), 0, h->st, B, h->status, h->alive, h->infeas);
+        // k_post_qp, k_eta, k_conv, k_post_conv and (first iteration) k_fix_beta in one launch
         EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff, h->stale, (i == 0 && sweep_shared_allowed()) ? 1 : 0};
-        hipLaunchKernelGGL(k_eta, dim3(B), dim3(256), 0, h->st, ea);
         ConvArgs ca{B, h->n, h->primal, h->prev_primal, h->has_prev, h->alive, h->conv, o.conv_tol};
-        hipLaunchKernelGGL(k_conv, dim3(B), dim3(64), 0, h->st, ca);
-        HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), h->st));
-        hipLaunchKernelGGL(k_post_conv, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->conv, h->alive, h->mask, h->success, h->itnum, h->counter, h->stale);
-        if (i == 0) hipLaunchKernelGGL(k_fix_beta, dim3(B), dim3(256), 0, h->st, d.N, d.ni, d.ni_f, o.eps_backoff, active, h->mask, h->stale, h->beta, h->beta_f);
+        if (!rti) HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), h->st));      // (the count of instances that go on is only read in converge mode)
+        AfterQpArgs aq{B, rti ? 1 : 0, i == 0 ? 1 : 0, h->status, active, h->alive, h->infeas, h->mask, h->success, h->itnum, h->counter, h->stale, h->conv, ea, ca, h->beta, h->beta_f};
+        hipLaunchKernelGGL(k_after_qp, dim3(B), dim3(256), 0, h->st, aq);
         const int tl_s = tl_begin(h, 1);
         if (launch_sweep(h, h->mask, h->eta, h->eta_f, o.eps_backoff, /* beta == eps for every column right after initialize_backoff */ i == 0)) return -1;
         tl_end(h, tl_s);

@@ -1,6 +1,12 @@
 import os
 import sys
 
+# numpy / scipy ship an OpenBLAS built for at most 64 threads; on hosts with more cores (the GPU boxes) its thread pool has crashed the test process
+# (segmentation faults inside scipy.linalg.lu_factor and, once, long after a BLAS call).  Keep the pool small from the moment the library loads --
+# this only takes effect if numpy has not been imported yet, the session fixture below covers the other case.
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")
+
 import numpy as np
 import pytest
 

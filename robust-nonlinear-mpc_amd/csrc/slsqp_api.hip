@@ -66,7 +66,7 @@ struct slsqp_handle {
     double *stage;     // staging buffer for host<->device transfers
     size_t stage_bytes;
     bool have_costs, have_cons, have_dyn;
-    bool beta_inited;           // beta / beta_f have been filled with eps once (k_init_backoff); later solves only repair swept instances (k_fix_beta)
+    bool beta_inited;           // beta / beta_f have been filled with eps once (k_init_backoff); later solves only repair swept instances (last part of k_after_qp)
     bool general_G;             // G, Gf are not [I;-I]: only the sweep-level boundary (slsqp_sweep) is available
     double *Gd, *Gfd;           // device copies of G (ni, nx+nu) and Gf (ni_f, nx) when general_G
     hipEvent_t ev[10];
@@ -322,23 +322,6 @@ extern "C" int slsqp_update_linear_cost(slsqp_handle *h, const double *q, int lo
 __global__ void k_fill_int(int *p, int v, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 __global__ void k_fill_doubles(double *p, double v, size_t n) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v; }
 __global__ void k_negate(const double *x, double *y, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) y[i] = -x[i]; }
-// after a QP: instances whose QP failed drop out (forward_solve -> False, fast_SLS_jit.py:461-464)
-__global__ void k_post_qp(int B, const int *status, int *alive, int *infeas) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && alive[b]) { const int ok = (status[b] == 0 || status[b] == 4); if (!ok) { alive[b] = 0; infeas[b] = 1; } }
-}
-// after the convergence test: mask = instances that go on to Riccati + tightening (_step :318-326)
-__global__ void k_post_conv(int B, int rti, const int *conv, int *alive, int *mask, int *success, int *itnum, int *counter, int *stale) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    int m = 0;
-    if (alive[b]) {
-        if (conv[b]) { success[b] = 1; if (!rti) alive[b] = 0; }
-        else m = 1;
-    }
-    mask[b] = m;
-    if (m) { itnum[b] += 1; stale[b] = (stale[b] & ~(2 | 32)) | 8; atomicAdd(counter, 1); }   // the sweep that follows rewrites this instance's K and beta
-}
 __global__ void k_finish(int B, int rti, const int *alive, const int *infeas, int *success, const int *active, int *pending_reset) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -357,16 +340,21 @@ __global__ void k_apply_pending_reset(int B, int *pending, const int *active, in
     __syncthreads();
     if (threadIdx.x == 0) { itnum[b] = 0; pending[b] = 0; stale[b] &= ~16; }
 }
-// The elementwise work between the first QP of a fast-SLS iteration and its sweep in ONE launch (one workgroup per instance), in the order of the
-// five launches it replaces: k_post_qp (a failed QP drops the instance), k_eta (evaluate_dual_eta), k_conv (check_convergence_socp), k_post_conv
-// (mask of the instances that go on to the sweep) and, in the first iteration, k_fix_beta.  A pendulum closed-loop step is launch-bound: 30 of its
-// ~120 launches were these.
+// The elementwise work between the first QP of a fast-SLS iteration and its sweep in ONE launch (one workgroup per instance), in the reference's order:
+//   a failed QP drops the instance (forward_solve -> False, fast_SLS_jit.py:461-464);
+//   evaluate_dual_eta (:475-487) -- in the first iteration of a solve beta = eps everywhere, eta[k,j] = mu_k / (2 sqrt(eps)) for every j <= k and only
+//     column 0 is written (all the shared Riccati recursion reads; slsqp_get broadcasts it on demand);
+//   check_convergence_socp (:581-600, its state persists across calls: quirk q5);
+//   the mask of the instances that go on to Riccati + tightening (_step :318-326);
+//   first iteration only: instances that are NOT swept but whose beta still holds an earlier solve's values get initialize_backoff's eps (the solve
+//     start no longer writes beta for everybody: 1.1 GB per 4096 rocket instances).
+// Five launches before; a pendulum closed-loop step is launch-bound and 30 of its ~120 launches were these.
 struct AfterQpArgs {
     int B, rti, first_iter;
     const int *status, *active;
     int *alive, *infeas, *mask, *success, *itnum, *counter, *stale, *conv;
     EtaArgs ea; ConvArgs ca;
-    double *beta_w, *beta_f_w;     // the same arrays as ea.beta / ea.beta_f, writable (k_fix_beta's part)
+    double *beta_w, *beta_f_w;     // the same arrays as ea.beta / ea.beta_f, writable (the beta repair)
 };
 __global__ __launch_bounds__(256) void k_after_qp(AfterQpArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -378,7 +366,7 @@ __global__ __launch_bounds__(256) void k_after_qp(AfterQpArgs a) {
     }
     __syncthreads();
     const int alive = s_alive;
-    if (alive) {       // ---- k_eta
+    if (alive) {       // ---- evaluate_dual_eta
         const EtaArgs &e = a.ea;
         const int SR = e.NX + e.NI, mb = e.N * SR + e.NIF;
         const double *du = e.dual + (size_t)b * mb;
@@ -397,7 +385,7 @@ __global__ __launch_bounds__(256) void k_after_qp(AfterQpArgs a) {
         }
     }
     int cv = 0;
-    if (tid < 64) {    // ---- k_conv (first wave)
+    if (tid < 64) {    // ---- check_convergence_socp (first wave)
         const ConvArgs &c = a.ca;
         if (alive) {
             const double *p = c.primal + (size_t)b * c.n;
@@ -410,8 +398,8 @@ __global__ __launch_bounds__(256) void k_after_qp(AfterQpArgs a) {
         if (tid == 0) {
             a.conv[b] = cv;
             int st = a.stale[b];
-            if (alive) st = a.ea.first_iter ? ((st & ~1) | 16) : (st & ~(1 | 16));      // what k_eta recorded about the eta array
-            int m = 0;                                                                    // ---- k_post_conv
+            if (alive) st = a.ea.first_iter ? ((st & ~1) | 16) : (st & ~(1 | 16));      // state of the eta array: column 0 only / complete
+            int m = 0;                                                                    // ---- mask
             if (alive) {
                 if (cv) { a.success[b] = 1; if (!a.rti) a.alive[b] = 0; }
                 else m = 1;
@@ -423,7 +411,7 @@ __global__ __launch_bounds__(256) void k_after_qp(AfterQpArgs a) {
         }
     }
     __syncthreads();
-    if (a.first_iter && !((a.active && !a.active[b]) || s_m || !(s_stale & 8))) {      // ---- k_fix_beta
+    if (a.first_iter && !((a.active && !a.active[b]) || s_m || !(s_stale & 8))) {      // ---- beta repair
         const EtaArgs &e = a.ea;
         double *be = a.beta_w + (size_t)b * e.N * e.N * e.NI, *bf = a.beta_f_w + (size_t)b * (e.N + 1) * e.NIF;
         for (int o = tid; o < e.N * e.N * e.NI; o += blockDim.x) be[o] = e.eps;
@@ -447,7 +435,7 @@ __global__ __launch_bounds__(256) void k_solve_begin(SolveBeginArgs a) {
     const int act = a.active ? a.active[b] : 1;
     if (a.x0 && tid < a.NX) a.x0val[(size_t)b * a.NX + tid] = -a.x0[(size_t)b * a.NX + tid];
     if (tid == 0) { a.alive[b] = act; a.infeas[b] = 0; a.success[b] = 0; }
-    if (a.pending[b] && act) {       // _finish_failure of the previous call (see k_apply_pending_reset)
+    if (a.pending[b] && act) {       // _finish_failure of the previous call (_finish_failure, fast_SLS_jit.py:334-341)
         for (size_t o = tid; o < a.neta; o += blockDim.x) a.eta[(size_t)b * a.neta + o] = 0.0;
         for (size_t o = tid; o < a.netaf; o += blockDim.x) a.eta_f[(size_t)b * a.netaf + o] = 0.0;
         __syncthreads();
@@ -464,7 +452,6 @@ __global__ __launch_bounds__(256) void k_solve_begin(SolveBeginArgs a) {
 }
 
 __global__ void k_reset_stale(int *p, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = (p[i] & 8) | 3; }   // eta, K: zero on demand; beta keeps its state
-__global__ void k_and_int(int *p, int v, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] &= v; }
 // instances whose `bit` is set in stale[]: zero their slice of arr1 (and arr2), then clear the bit (last use decides: clear_bit)
 __global__ void k_zero_stale(int *stale, int bit, double *arr1, size_t n1, double *arr2, size_t n2) {
     const int b = blockIdx.x;
@@ -694,7 +681,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         const int tl_q = tl_begin(h, 0);
         if (launch_qp(h, h->alive, &o, (i > 0 || o.warm_start) ? 1 : 0, nullptr, 0, 1, i > 0 ? 1 : 0, i == 0 ? wshift : 0)) return -1;
         tl_end(h, tl_q);
-        // k_post_qp, k_eta, k_conv, k_post_conv and (first iteration) k_fix_beta in one launch
+        // flags after the QP, evaluate_dual_eta, check_convergence_socp, masks and (first iteration) the beta repair: one launch
         EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff, h->stale, (i == 0 && sweep_shared_allowed()) ? 1 : 0};
         ConvArgs ca{B, h->n, h->primal, h->prev_primal, h->has_prev, h->alive, h->conv, o.conv_tol};
         if (!rti) HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), h->st));      // (the count of instances that go on is only read in converge mode)
@@ -785,7 +772,7 @@ extern "C" int slsqp_reset(slsqp_handle *h) {
     // `_prev_primal_vec` is NOT cleared by the reference (quirk q5) and is not cleared here.
     const slsqp_dims &d = h->d;
     const size_t B = h->B;
-    // eta, eta_f and K (1.5 GB at rocket B = 4096) are not cleared here: every entry the device reads is rewritten first (k_eta before the
+    // eta, eta_f and K (1.5 GB at rocket B = 4096) are not cleared here: every entry the device reads is rewritten first (evaluate_dual_eta before the
     // sweep, the sweep before anything reads K), so they are only marked stale and zeroed on demand when slsqp_get asks for them
     hipLaunchKernelGGL(k_reset_stale, dim3((h->B + 255) / 256), dim3(256), 0, h->st, h->stale, h->B);
     HIPCHK(hipMemsetAsync(h->itnum, 0, sizeof(int) * B, h->st));

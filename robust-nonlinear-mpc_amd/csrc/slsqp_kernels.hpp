@@ -1,17 +1,19 @@
 // slsqp_kernels.hpp -- device kernels of the batched fast-SLS QP path for gfx950 (MI355X).
 //
-// Mapping: ONE 64-lane wavefront per MPC instance (QP kernel) or per (instance, disturbance column)
-// (sweep kernel); workgroups are a single wave, so thousands of independent horizon recursions are in
-// flight and the scheduler interleaves them on every SIMD.  Stage blocks (A_k, B_k, Cholesky factors)
-// are staged HBM/L2 -> LDS with coalesced loads; small dense algebra runs out of LDS (wave_la.hpp).
+// Mapping: ONE 64-lane wavefront per MPC instance (QP kernel, shared Riccati recursion) or per (instance, disturbance column)
+// (propagation / general sweep kernels); workgroups are a single wave, so thousands of independent horizon recursions are in
+// flight and the scheduler interleaves them on every SIMD.  Stage blocks (A_k, B_k, stored inverses D_k^-1) are staged
+// HBM/L2 -> registers -> LDS with coalesced loads; the small dense algebra runs out of LDS / registers (wave_la.hpp).
 //
 // Reference behaviour restated here (citations relative to antoineleeman/robust-nonlinear-mpc):
-//   k_qp          the QP of QP.solve                 solver/qp_jit.py:362-402 (data layout :77-192)
-//   k_eta         evaluate_dual_eta                  solver/fast_SLS_jit.py:475-487
-//   k_sweep       _backward_solve_numba/_propagate/_backoff_from_phi (beta part)  :43-158
-//   k_tighten     _backoff_from_phi (sums) + update_tightening tail             :160-188, :556-569
-//   k_conv        check_convergence_socp             solver/fast_SLS_jit.py:581-600
-//   k_set_bounds  QP.update_dynamics + offset_constraints  solver/qp_jit.py:268-273, 595-610
+//   k_qp_solve                the QP of QP.solve            solver/qp_jit.py:362-402 (data layout :77-192)
+//   k_sweep_ric1 / _prop      _backward_solve_numba / _propagate / _backoff_from_phi (beta part), first fast-SLS iteration   fast_SLS_jit.py:43-158
+//   k_sweep / k_sweep_gen     the same for later iterations / a general constraint matrix G
+//   k_tighten                 _backoff_from_phi (sums) + update_tightening tail             :160-188, :556-569
+//   k_set_bounds              QP.update_dynamics + offset_constraints  solver/qp_jit.py:268-273, 595-610
+//   k_lin_val / _tan / _vec   SCP_SLS.update_jacobian       solver/SCP_SLS_jit.py:251-366
+//   k_cl_*                    socp_step, reset_warm_start, plant step of the closed-loop scripts   SCP_SLS_jit.py:404-551
+//   (evaluate_dual_eta :475-487 and check_convergence_socp :581-600 run inside k_after_qp, slsqp_api.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -1269,34 +1271,8 @@ __global__ void k_set_bounds(BoundsArgs a) {
 // sweep's values (not the eps of initialize_backoff); 16 eta / eta_f hold only column 0 of a first fast-SLS iteration (broadcast on demand);
 // 32 K is still in its compact form Kc (shared Riccati recursion; broadcast on demand)
 struct EtaArgs { int B, N, NX, NI, NIF; const double *dual, *beta, *beta_f; const int *run; double *eta, *eta_f; double eps; int *stale; int first_iter; };
-__global__ void k_eta(EtaArgs a) {
-    const int b = blockIdx.x;
-    if (a.run && !a.run[b]) return;
-    const int SR = a.NX + a.NI, mb = a.N * SR + a.NIF;
-    const double *du = a.dual + (size_t)b * mb;
-    double *et = a.eta + (size_t)b * a.N * a.N * a.NI;
-    double *ef = a.eta_f + (size_t)b * (a.N + 1) * a.NIF;
-    if (a.first_iter) {
-        // first iteration of a solve: beta = eps in every entry (initialize_backoff), so eta[k,j] = mu_k / (2 sqrt(eps)) for every j <= k.  Only
-        // column 0 is written -- all the shared Riccati recursion reads (k_sweep_ric1); slsqp_get broadcasts it when the array is asked for.
-        const double s0 = 2.0 * sqrt(a.eps);
-        for (int o = threadIdx.x; o < a.N * a.NI; o += blockDim.x) { const int i = o % a.NI, k = o / a.NI; et[((size_t)k * a.N) * a.NI + i] = du[k * SR + a.NX + i] / s0; }
-        for (int o = threadIdx.x; o < a.NIF; o += blockDim.x) ef[o] = du[a.N * SR + o] / s0;
-        if (a.stale && threadIdx.x == 0) a.stale[b] = (a.stale[b] & ~1) | 16;
-        return;
-    }
-    if (a.stale && threadIdx.x == 0) a.stale[b] &= ~(1 | 16);   // every entry with j <= k is rewritten below; the others are never written by anyone (zero)
-    const double *be = a.beta + (size_t)b * a.N * a.N * a.NI;
-    for (int o = threadIdx.x; o < a.N * a.N * a.NI; o += blockDim.x) {
-        const int i = o % a.NI, j = (o / a.NI) % a.N, k = o / (a.NI * a.N);
-        if (j <= k) et[o] = du[k * SR + a.NX + i] / (2.0 * sqrt(fmax(be[o], a.eps)));
-    }
-    const double *bf = a.beta_f + (size_t)b * (a.N + 1) * a.NIF;
-    for (int o = threadIdx.x; o < (a.N + 1) * a.NIF; o += blockDim.x) {
-        const int i = o % a.NIF;
-        ef[o] = du[a.N * SR + i] / (2.0 * sqrt(fmax(bf[o], a.eps)));
-    }
-}
+// (evaluate_dual_eta runs inside k_after_qp, slsqp_api.hip: first iteration of a solve -- beta = eps in every entry, so eta[k,j] = mu_k / (2 sqrt(eps))
+// for every j <= k and only column 0 is written, which is all the shared Riccati recursion reads; slsqp_get broadcasts it when the array is asked for)
 // eta[k,j] = eta[k,0] (1 <= j <= k), eta_f[j] = eta_f[0] for the instances whose arrays hold only column 0
 __global__ void k_eta_broadcast(int N, int NI, int NIF, int *stale, double *eta, double *eta_f) {
     const int b = blockIdx.x;
@@ -1323,31 +1299,11 @@ __global__ void k_K_broadcast(int N, int NUNX, int *stale, const double *Kc, dou
     __syncthreads();
     if (threadIdx.x == 0) stale[b] &= ~32;
 }
-// instances of this call that the first iteration does not sweep (failed QP, or quirk q5) but whose beta still holds an earlier solve's
-// values: initialize_backoff's eps, which the solve start no longer writes for everybody (1.1 GB per 4096 rocket instances)
-__global__ void k_fix_beta(int N, int NI, int NIF, double eps, const int *active, const int *mask, int *stale, double *beta, double *beta_f) {
-    const int b = blockIdx.x;
-    if ((active && !active[b]) || mask[b] || !(stale[b] & 8)) return;
-    for (int o = threadIdx.x; o < N * N * NI; o += blockDim.x) beta[(size_t)b * N * N * NI + o] = eps;
-    for (int o = threadIdx.x; o < (N + 1) * NIF; o += blockDim.x) beta_f[(size_t)b * (N + 1) * NIF + o] = eps;
-    __syncthreads();
-    if (threadIdx.x == 0) stale[b] &= ~8;
-}
-
 // ------------------------------------------------------------------------------------------------
 // check_convergence_socp (fast_SLS_jit.py:581-600): state persists across calls
 // ------------------------------------------------------------------------------------------------
 struct ConvArgs { int B, n; const double *primal; double *prev; int *has_prev; const int *run; int *conv; double tol; };
-__global__ void k_conv(ConvArgs a) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (a.run && !a.run[b]) { if (lane == 0) a.conv[b] = 0; return; }
-    const double *p = a.primal + (size_t)b * a.n;
-    double *q = a.prev + (size_t)b * a.n;
-    double d = 0.0;
-    for (int o = lane; o < a.n; o += 64) { d = fmax(d, fabs(p[o] - q[o])); q[o] = p[o]; }
-    d = wla::wave_max(d);
-    if (lane == 0) { a.conv[b] = (a.has_prev[b] && d <= a.tol) ? 1 : 0; a.has_prev[b] = 1; }
-}
+// (runs inside k_after_qp, slsqp_api.hip)
 
 // ------------------------------------------------------------------------------------------------
 // SLS sweep: one wave per (instance, disturbance column j)
@@ -2034,7 +1990,7 @@ __global__ void k_init_backoff(InitBackoffArgs a) {
     if (a.run && !a.run[b]) return;
     const int NZ = a.NX + a.NU, NI = 2 * NZ, NIF = 2 * a.NX, N = a.N;
     const double sq = sqrt(a.eps);
-    if (a.fill_beta) {   // only the handle's first solve: afterwards beta is eps wherever no sweep wrote, and k_fix_beta repairs the rest
+    if (a.fill_beta) {   // only the handle's first solve: afterwards beta is eps wherever no sweep wrote, and k_after_qp repairs the rest
         for (int o = threadIdx.x; o < N * N * NI; o += blockDim.x) a.beta[(size_t)b * N * N * NI + o] = a.eps;
         for (int o = threadIdx.x; o < (N + 1) * NIF; o += blockDim.x) a.beta_f[(size_t)b * (N + 1) * NIF + o] = a.eps;
     }

@@ -119,6 +119,8 @@ int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *op
    eta (N,N,ni) eta_f (N+1,ni_f) K (N,N+1,nu,nx) ubg (m-nx) lbg (m-nx) kkt (8) pin_dual (nx) success[int32] (1)
    and the current problem data: A (N,nx,nx) Bm (N,nx,nu) c (N,nx) g (N,ni) gN (ni_f) q (n) */
 int slsqp_get(slsqp_handle *h, const char *name, void *out, int loc);
+/* bytes slsqp_get copies per instance for `name` (the caller's buffer must hold batch x that), or -1 for an unknown name */
+long long slsqp_result_bytes(slsqp_handle *h, const char *name);
 /* Overwrite a named array: ubg, lbg (QP.update_ubg / reset_lbg, qp_jit.py:578-593, poked by SCP_SLS_jit.py:86-99), q, nominal_x, nominal_u,
    x_meas.  Same shapes as slsqp_get. */
 int slsqp_set(slsqp_handle *h, const char *name, const void *src, int loc);

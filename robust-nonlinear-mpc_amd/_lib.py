@@ -22,7 +22,7 @@ EXPORTS = [
     "slsqp_default_opts", "slsqp_last_error", "slsqp_version", "slsqp_create", "slsqp_destroy", "slsqp_set_costs",
     "slsqp_set_constraints", "slsqp_update_dynamics", "slsqp_update_linear_cost", "slsqp_solve", "slsqp_get", "slsqp_reset",
     "slsqp_sync", "slsqp_qp_nnz", "slsqp_qp_update_data_mat", "slsqp_qp_update_data_vec", "slsqp_qp_solve", "slsqp_sweep",
-    "slsqp_last_timing", "slsqp_kernel_timing", "slsqp_stream", "slsqp_set_model", "slsqp_set_E", "slsqp_linearize", "slsqp_cl_init", "slsqp_cl_step", "slsqp_nominal_solve", "slsqp_set", "slsqp_cl_log", "slsqp_selftest",
+    "slsqp_last_timing", "slsqp_kernel_timing", "slsqp_stream", "slsqp_set_model", "slsqp_set_E", "slsqp_linearize", "slsqp_cl_init", "slsqp_cl_step", "slsqp_nominal_solve", "slsqp_set", "slsqp_cl_log", "slsqp_selftest", "slsqp_result_bytes",
 ]
 
 _lib = None
@@ -57,6 +57,8 @@ def load():
     lib.slsqp_update_linear_cost.argtypes = [vp, dp, C.c_int]
     lib.slsqp_solve.argtypes = [vp, dp, C.c_int, C.POINTER(Opts)]
     lib.slsqp_get.argtypes = [vp, C.c_char_p, vp, C.c_int]
+    lib.slsqp_result_bytes.argtypes = [vp, C.c_char_p]
+    lib.slsqp_result_bytes.restype = C.c_longlong
     lib.slsqp_set.argtypes = [vp, C.c_char_p, vp, C.c_int]
     lib.slsqp_reset.argtypes = [vp]
     lib.slsqp_sync.argtypes = [vp]

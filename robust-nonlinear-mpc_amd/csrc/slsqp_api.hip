@@ -730,6 +730,12 @@ extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out8) {
     return 0;
 }
 
+// bytes per instance of a named result (what slsqp_get copies for each instance), or -1 for an unknown name
+extern "C" long long slsqp_result_bytes(slsqp_handle *h, const char *name) {
+    auto it = h->named.find(name);
+    return it == h->named.end() ? -1LL : (long long)it->second.second;
+}
+
 extern "C" int slsqp_get(slsqp_handle *h, const char *name, void *out, int loc) {
     hipSetDevice(h->dev);
     auto it = h->named.find(name);

@@ -192,6 +192,9 @@ class BatchedFastSLS:
 
     def get(self, name, shape, dtype=np.float64):
         out = np.empty((self.B,) + tuple(shape), dtype=dtype)
+        want = self.lib.slsqp_result_bytes(self.h, name.encode())
+        if want >= 0 and want * self.B != out.nbytes:      # the library copies `want` bytes per instance: a smaller buffer would be overrun
+            raise ValueError(f"result {name!r}: the library holds {want} bytes per instance, shape {tuple(shape)} of {np.dtype(dtype)} is {out.nbytes // max(1, self.B)}")
         L.check(self.lib.slsqp_get(self.h, name.encode(), out.ctypes.data_as(C.c_void_p), L.HOST))
         return out
 

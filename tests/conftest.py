@@ -7,6 +7,9 @@ import sys
 # this only takes effect if numpy has not been imported yet, the session fixture below covers the other case.
 for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, "1")
+# ... and still about once in fifteen runs with one thread, always inside dgetrf: the GPU hosts are Zen 5 (EPYC 9575F), for which these OpenBLAS
+# builds (0.3.28 / 0.3.29, DYNAMIC_ARCH) select their AVX-512 "SkylakeX" kernels.  The AVX2 "Haswell" kernels are the ones every other x86 host runs.
+os.environ.setdefault("OPENBLAS_CORETYPE", "Haswell")
 
 import numpy as np
 import pytest

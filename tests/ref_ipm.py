@@ -27,15 +27,6 @@ def build_equalities(A, B, c, x0val):
 
 
 def qp_box(Pd, q, E, e, lo, hi, tol=1e-12, max_it=100):
-    try:       # see conftest._limit_blas_threads: also for callers outside pytest (scripts/)
-        from threadpoolctl import threadpool_limits
-        with threadpool_limits(limits=1):
-            return _qp_box(Pd, q, E, e, lo, hi, tol, max_it)
-    except ImportError:
-        return _qp_box(Pd, q, E, e, lo, hi, tol, max_it)
-
-
-def _qp_box(Pd, q, E, e, lo, hi, tol=1e-12, max_it=100):
     n = len(q)
     fu, fl = hi < 1e19, lo > -1e19
     K = np.block([[np.diag(Pd), E.T], [E, np.zeros((E.shape[0], E.shape[0]))]])

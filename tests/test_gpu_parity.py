@@ -864,3 +864,13 @@ def test_infeasible_box_is_flagged_early_by_the_stagnation_rule():
     assert qs[2, 0, 1] < 110
     ok = [b for b in range(B) if b != 2]
     assert (st[ok] == 0).all() and np.array_equal(x[ok], xr[ok])
+
+
+def test_python_mirror_under_debug_allocators():
+    """Every entry point of the Python mirror that hands a host buffer to the C ABI, once, in a child process whose allocators check their block
+    boundaries (glibc MALLOC_CHECK_=3, PYTHONMALLOC=malloc_debug): an undersized buffer aborts the child instead of corrupting a heap silently."""
+    import subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, MALLOC_CHECK_="3", PYTHONMALLOC="malloc_debug")
+    r = subprocess.run([sys.executable, "-X", "faulthandler", os.path.join(ROOT, "tests", "abi_memcheck.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "abi_memcheck ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])

@@ -304,3 +304,35 @@ def test_bench_qp_statistics_are_over_the_solves_that_ran():
     assert out["qp2"]["infeasible_x0_frac"] == 1 / 8 and out["qp2"]["not_run_frac"] == 1 / 8 and out["qp2"]["ran_frac"] == 6 / 8
     assert out["qp1"]["block_solves_mean"] == 5 and out["qp2"]["block_solves_mean"] == 5 and out["qp2"]["certified_frac"] == 1.0
     assert out["qp2"]["active_inequalities"]["histogram_per_step"]["counts"][0][1] == 3        # three solves of step 0 ran, 3 active rows each
+
+
+def test_ctypes_struct_layouts_match_the_header(tmp_path):
+    """slsqp_opts / slsqp_dims as the Python mirror declares them against the C header, field by field (gcc + offsetof): a field added on one side
+    only would make slsqp_default_opts write past the Python object."""
+    import ctypes as C
+    import subprocess
+    from robust_nonlinear_mpc_amd import _lib as L
+    fields = {"slsqp_opts": [n for n, _ in L.Opts._fields_], "slsqp_dims": [n for n, _ in L.Dims._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "slsqp.h"', 'int main(void) {']
+    for st, names in fields.items():
+        src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        src += [f'  printf("{st}.{n} %zu\\n", offsetof({st}, {n}));' for n in names]
+    src += ['  return 0;', '}']
+    cfile = tmp_path / "layout.c"
+    cfile.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(cfile)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert int(got["slsqp_opts"]) == C.sizeof(L.Opts) and int(got["slsqp_dims"]) == C.sizeof(L.Dims)
+    for cls, st in ((L.Opts, "slsqp_opts"), (L.Dims, "slsqp_dims")):
+        for n in fields[st]:
+            assert int(got[f"{st}.{n}"]) == getattr(cls, n).offset, (st, n)
+    # and the header has no field the mirror lacks: count the members of the struct bodies
+    hdr = open(os.path.join(ROOT, "include", "slsqp.h")).read()
+    for st in fields:
+        body = hdr[:hdr.index("} " + st + ";")]
+        body = body[body.rindex("typedef struct"):]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        decl = [d for d in body.split(";") if re.search(r"\b(int|double)\b", d)]
+        n_members = sum(len(d.split(",")) for d in decl)
+        assert n_members == len(fields[st]), (st, n_members, len(fields[st]))

@@ -6,13 +6,16 @@ A "step" is one closed-loop MPC step of the whole batch, entirely on the device 
     warm-start shift + solver reset -> linearise (RK4 + forward-mode AD) -> fast-SLS RTI solve (QP #1, eta, SLS sweep, tightening,
     QP #2; rti = 1, fast_sls_rti_steps = 1 as in expe/main_rocket_robust_closed_loop.py:80-85) -> nominal += delta -> plant + noise
 for 4096 rocket runs per GPU that differ in their disturbance seed (BASELINE config 5's shape: seed s reproduces the stream of
-np.random.seed(s), w_t = 2 rand(17) - 1), started from the script's initial state scaled to 0.3 of its distance from hover, nominal
-from the GPU initialiser (untimed set-up).  Warm-up steps are the first closed-loop steps, the timed steps the ones that follow.
-value = QP solves / s over all ranks (weak scaling: every rank owns its own 4096 seeds; the only collective is one RCCL all-gather
+np.random.seed(s), w_t = 2 rand(17) - 1), started from THE SCRIPT'S OWN INITIAL STATE (expe/main_rocket_robust_closed_loop.py:110-126), nominal
+from the GPU initialiser (untimed set-up, the role IPOPT has in the script).  The timed steps are closed-loop steps 0 .. K-1 exactly as the
+script runs them (default K = 30, :128): `--warmup W` runs W untimed closed-loop steps of a DISJOINT seed batch of the same size first, so
+the warm-up never shifts which steps are timed.
+value = QP solves / s over all ranks (weak scaling: every rank owns its own seeds; the only collective is one RCCL all-gather
 of the measured states and applied inputs at the end of the timed region).
 
-`--workload synthetic` times round 1's step (seeded synthetic instances, update_dynamics + update_linear_cost + solve); the default
-run reports it as a labelled secondary figure.
+Secondary figures of the default run (labelled, after the timed region): the same loop from the state scaled to 0.3 of its distance from
+hover (round 2's headline regime: few active bounds), and the whole batch as one slice.  `--workload synthetic` times round 1's step.
+`--config 5` = BASELINE config 5's per-GPU shape: 1024 seeds per rank (8192 on 8 ranks), script x0, 30 steps.
 """
 import argparse
 import json
@@ -28,15 +31,19 @@ sys.path.insert(0, ROOT)
 FIXTURE = {"rocket": "sweep_rocket_N20_s0.npz", "quadrotor": "sweep_quadrotor_N20_s0.npz", "pendulum": "sweep_pendulum_N10_s0.npz"}
 QP_BYTES = {"rocket": 93656, "quadrotor": 64504, "pendulum": 6112}     # algorithmic bytes per QP solve
 SWEEP_MFLOP = 9.0                                                      # per rocket N=20 instance, scaled with nx^3 N^2 otherwise
-X0_SCALE = {"rocket": 0.3, "quadrotor": 1.0, "pendulum": 1.0}
+X0_SCALE = {"rocket": 1.0, "quadrotor": 1.0, "pendulum": 1.0}      # 1.0 = the script's own initial state
+X0_SCALE_SECONDARY = 0.3                                               # round 2's headline regime, kept as a labelled secondary figure
+WARM_SEED0 = 1 << 20                                                   # warm-up batches use seeds from here on (disjoint from every rank's own)
+PROFILE_DIR = "r03"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=30, help="timed closed-loop steps 0 .. steps-1 (the rocket script runs 30)")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed closed-loop steps of a disjoint seed batch before the timed region")
+    ap.add_argument("--batch", type=int, default=None, help="instances (seeds) per GPU; default 4096")
+    ap.add_argument("--config", type=int, default=None, choices=[5], help="5: BASELINE config 5's per-GPU shape (--batch 1024 --x0-scale 1.0 --steps 30)")
     ap.add_argument("--model", default="rocket")
     ap.add_argument("--workload", default="closed_loop", choices=["closed_loop", "synthetic"])
     ap.add_argument("--no-cpu", action="store_true")
@@ -45,9 +52,17 @@ def parse():
     ap.add_argument("--qp-eps", type=float, default=None, help="interior-point tolerance before the polish (default: the library's 1e-6)")
     ap.add_argument("--precision", type=int, default=0, help="0: fp64 (headline); 1: mixed fp32 factorisation / fp64 residuals (secondary figure)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
-    ap.add_argument("--x0-scale", type=float, default=None, help="closed loop: initial state = hover + s (script x0 - hover); default 0.3 for the rocket (1.0 = the script's own "
-                    "state: the nominal initialiser then runs its two-stage continuation)")
-    return ap.parse_args()
+    ap.add_argument("--x0-scale", type=float, default=None, help="closed loop: initial state = hover + s (script x0 - hover); default 1.0 = the script's own state "
+                    "(the nominal initialiser then runs its two-stage continuation)")
+    ap.add_argument("--secondary-synthetic", action="store_true", help="also time round 1's synthetic step as a secondary figure")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the all-core leg of cpu_baseline")
+    args = ap.parse_args()
+    if args.config == 5:
+        args.batch = 1024 if args.batch is None else args.batch
+        args.x0_scale = 1.0 if args.x0_scale is None else args.x0_scale
+    if args.batch is None:
+        args.batch = 4096
+    return args
 
 
 def launch_ranks(args):
@@ -65,31 +80,33 @@ def launch_ranks(args):
 # --------------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle; C threads)
 # --------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(m, N, data, budget_s=10.0):
+def cpu_baseline(m, N, data, sample, budget_s=12.0):
     """The oracle's RTI fast-SLS step (OSQP-class ADMM restatement with upstream default settings + polish, numba-kernel restatement for the
-    sweep) on the first instances of the SAME QPs the GPU solved in its last timed step, driven by C threads (oracle/sls_oracle.c
-    so_rti_step_batch: no interpreter lock): one thread, then one instance per thread on all host cores this process may use."""
+    sweep) on QPs the GPU solved, SAME data, driven by C threads (oracle/sls_oracle.c so_rti_step_batch: no interpreter lock): one thread,
+    then one instance per thread on all host cores this process may use.  `sample` says which QPs `data` holds."""
     from oracle import oracle as O
     d = O.dims_of(m.nx, m.nu, m.nw, N, m.ni, m.ni_f)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
     import numpy as np
     E = np.stack([m.E] * (N + 1))
-    args = (d, data["A"], data["Bm"], data["g"], data["gN"], data["c"], data["q"], data["x0_arg"], m.G, m.Gf, m.gf, E, m.Q, m.R, m.Qf,
-            m.Q_reg, m.R_reg, m.Q_reg_f, O.default_settings())
+    n_inst = data["A"].shape[0]
 
-    def run(threads, budget):
+    def run(threads, budget, sel):
+        args = (d, data["A"][sel], data["Bm"][sel], data["g"][sel], data["gN"][sel], data["c"][sel], data["q"][sel], data["x0_arg"][sel], m.G, m.Gf, m.gf, E,
+                m.Q, m.R, m.Qf, m.Q_reg, m.R_reg, m.Q_reg_f, O.default_settings())
         t0 = time.perf_counter()
         _, ok, done = O.rti_step_batch(*args, nthreads=threads, budget_s=budget)
         dt = time.perf_counter() - t0
         return 2 * done / dt, done, dt, float(ok[:done].mean()) if done else 0.0
 
-    v1, n1, t1, ok1 = run(1, 0.6 * budget_s)
-    vc, nc, tc, okc = (v1, n1, t1, ok1) if cores == 1 else run(cores, budget_s)
-    return {"value": vc, "unit": "QP solves/s", "cores": cores, "kind": "port", "single_thread_value": v1, "solved_frac": okc,
-            "sample": f"the QPs of the GPU's last timed step (first instances of rank 0 whose step the GPU solved), 1 RTI MPC step (2 QP + 1 sweep) each, OSQP-class restatement "
-                      f"with upstream default settings + polish, C threads: {nc} instances on {cores} threads in {tc:.1f} s; {n1} instances on 1 thread "
-                      f"in {t1:.1f} s"}
+    # one thread: a strided sub-sample, so that a budget that ends early has still seen every sampled step
+    stride = max(1, n_inst // 48)
+    v1, n1, t1, ok1 = run(1, 0.5 * budget_s, np.arange(0, n_inst, stride))
+    vc, nc, tc, okc = (v1, n1, t1, ok1) if cores == 1 else run(cores, budget_s, np.arange(n_inst))
+    return {"value": vc, "unit": "QP solves/s", "cores": cores, "kind": "port", "single_thread_value": v1, "solved_frac": okc, "single_thread_solved_frac": ok1,
+            "sample": f"{sample}; 1 RTI MPC step (2 QP + 1 sweep) each, OSQP-class restatement with upstream default settings + polish, C threads: "
+                      f"{nc} of {n_inst} instances on {cores} threads in {tc:.1f} s; {n1} instances (every {stride}th) on 1 thread in {t1:.1f} s"}
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -115,6 +132,7 @@ class ClosedLoopSlices:
         torch.cuda.synchronize()
         self.step_no = 0
         self.stats = [[] for _ in self.cl]       # per slice: list over steps of qp_stats (b,2,8)
+        self.step_ms = [[] for _ in self.cl]     # per slice: GPU ms of every step run so far (HIP events of slsqp_cl_step)
 
     def setup(self, x0, continuation=1):
         import numpy as np
@@ -157,6 +175,7 @@ class ClosedLoopSlices:
                 t = f.timing_ms()
                 for key in acc[k]:
                     acc[k][key] += t[key]
+                self.step_ms[k].append(t["total"])
                 if collect_stats:
                     self.stats[k].append(f.get("qp_stats", (2, 8), np.int32))
         self._threads(work)
@@ -229,14 +248,78 @@ def qp_statistics(stats):
     return out
 
 
-def read_traffic(fname, key):
-    p = os.path.join(ROOT, "profiles", "r02", fname)
+def bench_command(args, n_slices, x0_scale):
+    """What a PMC pass must have been taken on to describe this run (profiles/<round>/pmc_traffic*.json hold the same dict under "command")."""
+    return {"model": args.model, "batch": args.batch, "steps": args.steps, "warmup": args.warmup, "slices": n_slices, "x0_scale": x0_scale,
+            "precision": args.precision, "workload": args.workload}
+
+
+def read_traffic(fname, key, command):
+    """HBM bytes per launch from the committed PMC passes -- only when they were taken on exactly this command; otherwise null."""
+    p = os.path.join(ROOT, "profiles", PROFILE_DIR, fname)
     if not os.path.exists(p):
-        return None, None
+        return None, f"no PMC pass in profiles/{PROFILE_DIR}/{fname}"
     d = json.load(open(p))
+    if d.get("command") != command:
+        return None, f"profiles/{PROFILE_DIR}/{fname} is of another command ({d.get('command')}): not attached"
     if key + "_timed_region" in d:      # per launch of the timed region's launches only (the file also averages the untimed set-up's)
         key = key + "_timed_region"
-    return d.get(key), f"profiles/r02/{fname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this round, scripts/pmc_traffic.py; build {d.get('build', '?')})"
+    return d.get(key), f"profiles/{PROFILE_DIR}/{fname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scripts/pmc_traffic.py; build {d.get('build', '?')})"
+
+
+def reduce_over_ranks(dt, qp_done, world, backend):
+    """The timed region's wall time is the slowest rank's, the work the sum over ranks (torch.distributed all_reduce; no-op for one rank)."""
+    if world <= 1:
+        return dt, qp_done
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if backend == "nccl" else "cpu"
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tsum = torch.tensor([qp_done], device=dev, dtype=torch.float64)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    return float(tmax.item()), float(tsum.item())
+
+
+def gather_results(t, world, backend):
+    """The only collective of the path: one all-gather of the measured states and applied inputs (RCCL over xGMI with backend nccl)."""
+    if world <= 1:
+        return t
+    import torch
+    import torch.distributed as dist
+    src = t if backend == "nccl" else t.cpu()
+    out = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(out, src)
+    return out
+
+
+QP_DATA_KEYS = ("A", "Bm", "c", "g", "gN", "q", "x0_arg")
+
+
+def sample_qp_data(m, N, seeds, x0, cont, steps, every, local_rank, tune, ClosedLoopSlicesCls):
+    """The CPU baseline's sample: the closed loops of `seeds` run again as their own small batch (bit-identical to their run inside the big one: instances
+    are independent) and the QP data of every `every`-th step is fetched for the instances whose two QPs the GPU solved in that step."""
+    import numpy as np
+    n_var = (m.nx + m.nu) * N + m.nx
+    shapes = {"A": (N, m.nx, m.nx), "Bm": (N, m.nx, m.nu), "c": (N, m.nx), "g": (N, m.ni), "gN": (m.ni_f,), "q": (n_var,), "x0_arg": (m.nx,)}
+    small = ClosedLoopSlicesCls(m, N, seeds, 1, steps, local_rank, tune)
+    small.setup(x0, cont)
+    parts, taken = {k: [] for k in QP_DATA_KEYS}, []
+    for i in range(steps):
+        small.run(1, collect_stats=False)
+        if i % every:
+            continue
+        f0 = small.cl[0].f
+        qs = f0.get("qp_stats", (2, 8), np.int32)
+        sel = np.flatnonzero(np.isin(qs[:, 0, 6], (0, 4)) & np.isin(qs[:, 1, 6], (0, 4)))
+        taken.append((i, int(sel.size)))
+        for k in QP_DATA_KEYS:
+            parts[k].append(f0.get(k, shapes[k])[sel])
+    small.close()
+    data = {k: np.concatenate(v) for k, v in parts.items()}
+    # interleave the steps, so that a CPU budget that ends early has seen all of them
+    order = np.argsort(np.concatenate([np.arange(n) for _, n in taken]), kind="stable")
+    return {k: v[order] for k, v in data.items()}, taken
 
 
 def main():
@@ -289,12 +372,7 @@ def main():
         torch.cuda.synchronize()
 
     def gather(t):
-        if world > 1:
-            src = t if args.backend == "nccl" else t.cpu()
-            out = [torch.empty_like(src) for _ in range(world)]
-            dist.all_gather(out, src)                 # RCCL over xGMI: the only collective of the path
-            return out
-        return t
+        return gather_results(t, world, args.backend)
 
     def make_synth(n_slices, seed):
         batch = make_batch(args.model, fixture, B, seed=seed)
@@ -328,16 +406,25 @@ def main():
                 "hbm": {"algorithmic_bytes_per_launch": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "frac_of_8TBps": alg / (ms * 1e-3) / 8e12 if ms > 0 else 0.0,
                         "sweep_bytes_per_launch": work, "sweep_GBps": work / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}}
 
+    def x0_of(scale):
+        return m.x_ref + scale * (m.extra["x0"] - m.x_ref) if "x0" in m.extra else m.x_ref + 0.02 * (m.x_ub - m.x_lb)
+
     out = {}
+    x0_scale = X0_SCALE[args.model] if args.x0_scale is None else args.x0_scale
+    cont = 2 if x0_scale > 0.6 else 1
     if args.workload == "closed_loop":
         seeds = rank * B + np.arange(B)
-        x0_scale = X0_SCALE[args.model] if args.x0_scale is None else args.x0_scale
-        cont = 2 if x0_scale > 0.6 else 1
-        x0 = m.x_ref + x0_scale * (m.extra["x0"] - m.x_ref) if "x0" in m.extra else m.x_ref + 0.02 * (m.x_ub - m.x_lb)
-        dev = ClosedLoopSlices(m, N, seeds, args.slices, args.warmup + args.steps, local_rank, tune)
+        x0 = x0_of(x0_scale)
+        if args.warmup > 0:
+            # warm the code paths (kernel code objects, allocator, clocks, the gather) on a DISJOINT seed batch of the same size: the timed region
+            # below is then closed-loop steps 0 .. steps-1 of the rank's own seeds whatever --warmup says
+            wdev = ClosedLoopSlices(m, N, WARM_SEED0 + rank * B + np.arange(B), args.slices, args.warmup, local_rank, tune)
+            wdev.setup(x0, cont)
+            wdev.run(args.warmup, collect_stats=False)
+            gather(torch.cat([wdev.fetch_device("x_meas", (m.nx,)), wdev.fetch_device("u0", (m.nu,))], dim=1))     # warm the gather path
+            wdev.close()
+        dev = ClosedLoopSlices(m, N, seeds, args.slices, args.steps, local_rank, tune)
         nlp = dev.setup(x0, cont)
-        dev.run(args.warmup, collect_stats=False)
-        gather(torch.cat([dev.fetch_device("x_meas", (m.nx,)), dev.fetch_device("u0", (m.nu,))], dim=1))     # warm the gather path
         barrier()
         dev.kernel_timing()
         t0 = time.perf_counter()
@@ -345,16 +432,26 @@ def main():
         gather(torch.cat([dev.fetch_device("x_meas", (m.nx,)), dev.fetch_device("u0", (m.nu,))], dim=1))
         barrier()
         dt = time.perf_counter() - t0
-        workload = (f"{args.model} N={N} batch={B}/GPU closed-loop Monte-Carlo, one slsqp_cl_step per step (shift + reset, linearise, fast-SLS RTI: 2 QP solves + 1 SLS "
-                    f"sweep per instance, nominal update, plant + seeded noise); x0 = hover + {x0_scale} (script x0 - hover), nominal from the GPU "
-                    f"initialiser (untimed); timed steps = closed-loop steps {args.warmup}..{args.warmup + args.steps - 1}")
-        qstat = qp_statistics([np.concatenate([dev.stats[k][s] for k in range(len(dev.cl))]) for s in range(args.steps)])
+        x0_txt = "the script's own initial state (expe/main_rocket_robust_closed_loop.py:110-126)" if (x0_scale == 1.0 and args.model == "rocket") else \
+            f"hover + {x0_scale} (script x0 - hover)"
+        workload = (f"{args.model} N={N} batch={B}/GPU closed-loop Monte-Carlo from script x0" if (x0_scale == 1.0 and "x0" in m.extra) else
+                    f"{args.model} N={N} batch={B}/GPU closed-loop Monte-Carlo")
+        workload += (f": one slsqp_cl_step per step (shift + reset, linearise, fast-SLS RTI: {m.rti * (m.fast_sls_rti_steps + 1)} QP solves + "
+                     f"{m.rti * m.fast_sls_rti_steps} SLS sweep(s) per instance, nominal update, plant + seeded noise); x0 = {x0_txt}, nominal from the GPU "
+                     f"initialiser (untimed); timed steps = closed-loop steps 0..{args.steps - 1}; warm-up = {args.warmup} step(s) of a disjoint seed batch")
+        per_step = [np.concatenate([dev.stats[k][s] for k in range(len(dev.cl))]) for s in range(args.steps)]
+        qstat = qp_statistics(per_step)
         succ = dev.get("scp_success", (), np.int32)
+        step_ms = np.mean(np.array(dev.step_ms), axis=0)          # per closed-loop step: GPU ms of slsqp_cl_step, mean over the rank's slices (they run concurrently)
         extra_cfg = {"nominal_initialiser_converged_frac": float((nlp == 0).mean()), "mpc_step_success_frac_last_step": float(succ.mean()), "qp": qstat,
-                     "linearise_ms_per_step": float(np.mean([a["jac"] for a in acc])) / args.steps}
+                     "linearise_ms_per_step": float(np.mean([a["jac"] for a in acc])) / args.steps,
+                     "per_step": {"slice_gpu_ms": [round(float(v), 3) for v in step_ms],
+                                  "qp_solves_run": [int(((st[:, :, 6] != -1) & (st[:, :, 6] != 2)).sum()) for st in per_step],
+                                  "note": "slice_gpu_ms: HIP-event time of one slice's slsqp_cl_step, mean over the slices of rank 0; slices overlap, so the sum "
+                                          "over steps exceeds the wall time"}}
     else:
         dev, batch = make_synth(args.slices, 1234 + rank)
-        dev.run(args.warmup)
+        dev.run(max(1, args.warmup))
         gather(dev.fetch_device("primal_vec", (n_var,))[:, m.nx:m.nx + m.nu].contiguous())
         barrier()
         dev.kernel_timing()
@@ -369,13 +466,7 @@ def main():
     k_ms, k_launches, inst_sweeps, mx_retries = dev.kernel_timing()
     fact_stages, qp_solves = dev.factor_stages, dev.qp_solves
     qp_done = float(qp_solves)      # QP solves of the timed region that actually ran (device counter), this rank
-    if world > 1:
-        tmax = torch.tensor([dt], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        tsum = torch.tensor([qp_done], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        qp_done = float(tsum.item())
+    dt, qp_done = reduce_over_ranks(dt, qp_done, world, args.backend)
     n_sl = len(dev.bounds)
     # QP solves per instance and step: closed loop = rti SCP iterations x (fast_sls_rti_steps + 1) QPs (rocket script: 1 x 2; pendulum / quadrotor: 3 x 3)
     qp_per_inst = (m.rti * (m.fast_sls_rti_steps + 1)) if args.workload == "closed_loop" else ((m.fast_sls_rti_steps if args.model == "rocket" else 1) + 1)
@@ -383,9 +474,9 @@ def main():
     # nominal touches) is flagged infeasible before any work, as the reference's QP would be, and its two QPs are not counted
     qp_nominal = qp_per_inst * B * world * args.steps
     value = qp_done / dt
-    headline = (args.model, B, args.workload) == ("rocket", 4096, "closed_loop")
+    headline = (args.model, B, args.workload, x0_scale) == ("rocket", 4096, "closed_loop", 1.0)
     out = {
-        "metric": ("QP solves/sec (whole node), rockETH N=20 batch=4096 closed-loop RTI MPC step" if headline
+        "metric": ("QP solves/sec (whole node), rockETH N=20 batch=4096 closed-loop RTI MPC step from script x0" if headline
                    else f"QP solves/sec (whole node), {args.model} N={N} batch={B} {args.workload} RTI MPC step"), "value": value, "unit": "QP solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 0 else "f32 factorisation + f64 residuals (mixed)",
@@ -400,9 +491,9 @@ def main():
         # dominant kernel: k_qp_solve; time = HIP events around every launch on the launching stream (opts.time_kernels), work = device counters.
         # The kernel is bound by vector-ALU instruction issue: its roof is the fp64 peak (matrix = vector = 78.6 TFLOP/s).
         rb = roof_block(k_ms, k_launches, inst_sweeps, fact_stages, qp_solves)
-        # the committed PMC passes are of the default command: attach them only to a run of that workload (and slice count)
-        pmc_ok = headline and args.precision == 0 and args.x0_scale is None      # (the passes timed closed-loop steps 1..5: --steps 5 --warmup 1)
-        traffic, tsrc = read_traffic("pmc_traffic.json", "k_qp_solve_bytes_per_launch") if (pmc_ok and n_sl == 3) else (None, "no PMC pass of this configuration in profiles/r02")
+        # HBM traffic from PMC counters: attached only when the committed passes were taken on exactly this command
+        command = bench_command(args, n_sl, x0_scale)
+        traffic, tsrc = read_traffic("pmc_traffic.json", "k_qp_solve_bytes_per_launch", command)
         calls = args.steps * n_sl
         sweep_flop = SWEEP_MFLOP * 1e6 * (m.nx / 17.0) ** 3 * (N / 20.0) ** 2
         step_tf = (fact_stages * kf + 2.0 * inst_sweeps * N * ks + args.steps * B * sweep_flop) / dt / 1e12
@@ -414,29 +505,29 @@ def main():
             # the whole step: fp64 work of the timed region (QP kernel + 9.0 Mflop per rocket instance for the SLS sweep) over wall time
             "whole_step_fp64": {"achieved_TFLOPs": step_tf, "peak_TFLOPs": 78.6, "frac": step_tf / 78.6},
             "sweep_avg_launch_ms": sum(a["sweep"] for a in acc) / calls, "slice_gpu_ms_per_step": [round(a["total"] / args.steps, 2) for a in acc]})
-        cpu_data = None
-        if args.workload == "closed_loop" and not args.no_cpu and world == 1:
-            f0 = dev.cl[0].f
-            # the CPU gets the instances whose two QPs the GPU solved in that step (steps flagged infeasible at x0 cost neither side any work)
-            qs0 = f0.get("qp_stats", (2, 8), np.int32)
-            sel = np.flatnonzero((qs0[:, 0, 6] == 0) & (qs0[:, 1, 6] == 0))[:1024]
-            if sel.size < 64:      # (a step in which hardly any instance was solved: take the first instances as they are)
-                sel = np.arange(min(f0.B, 1024))
-            cpu_data = {k: f0.get(k, shp)[sel] for k, shp in (("A", (N, m.nx, m.nx)), ("Bm", (N, m.nx, m.nu)), ("c", (N, m.nx)), ("g", (N, m.ni)), ("gN", (m.ni_f,)),
-                                                               ("q", (n_var,)), ("x0_arg", (m.nx,)))}
-        elif args.workload == "synthetic" and not args.no_cpu and world == 1:
+        cpu_data, cpu_sample = None, ""
+        if args.workload == "synthetic" and not args.no_cpu:
             ncpu = min(B, 1024)
             cpu_data = {"A": batch["A"][:ncpu], "Bm": batch["B"][:ncpu], "c": batch["c"][:ncpu], "g": batch["g"][:ncpu], "gN": batch["gN"][:ncpu], "q": batch["q"][:ncpu],
                         "x0_arg": batch["x0_arg"][:ncpu]}
+            cpu_sample = f"the first {ncpu} synthetic instances of rank 0"
         dev.close()
+        if args.workload == "closed_loop" and not args.no_cpu:
+            try:
+                # QPs sampled ACROSS the timed steps: the first 32 seeds of rank 0, every third closed-loop step
+                ns, every = min(32, B), 3
+                cpu_data, taken = sample_qp_data(m, N, seeds[:ns], x0, cont, args.steps, every, local_rank, tune, ClosedLoopSlices)
+                cpu_sample = (f"the MPC steps of seeds {int(seeds[0])}..{int(seeds[ns - 1])} at closed-loop steps {[t for t, _ in taken]} of the timed run whose two QPs the GPU "
+                              f"solved ({[c for _, c in taken]} instances per step; the steps interleaved)")
+            except Exception as e:
+                cpu_data, cpu_sample = None, repr(e)
         if not args.no_secondary and world == 1:
             try:
                 # the same kernels with the whole batch in ONE slice (no concurrent launches) after the timed region: with several slices the HIP-event
                 # duration of a launch includes the time it shares the GPU with the other slices' launches
                 if n_sl > 1 and args.workload == "closed_loop":
-                    one = ClosedLoopSlices(m, N, seeds, 1, args.warmup + args.steps, local_rank, tune)
+                    one = ClosedLoopSlices(m, N, seeds, 1, args.steps, local_rank, tune)
                     one.setup(x0, cont)
-                    one.run(args.warmup, collect_stats=False)
                     torch.cuda.synchronize()
                     one.kernel_timing()
                     t1 = time.perf_counter()
@@ -446,14 +537,35 @@ def main():
                     ms1, n1, sw1, _ = one.kernel_timing()
                     fs1, qs1 = one.factor_stages, one.qp_solves
                     one.close()
-                    tr1, ts1 = read_traffic("pmc_traffic_single_slice.json", "k_qp_solve_bytes_per_launch") if pmc_ok else (None, "no PMC pass of this configuration in profiles/r02")
+                    tr1, ts1 = read_traffic("pmc_traffic_single_slice.json", "k_qp_solve_bytes_per_launch", bench_command(args, 1, x0_scale))
                     out["roofline"]["single_slice"] = dict(roof_block(ms1, n1, sw1, fs1, qs1), traffic=tr1, traffic_source=ts1, ms_per_step=1e3 * dt1 / args.steps,
                                                            gpu_ms_per_step={k: a1[0][k] / args.steps for k in a1[0]},
                                                            note="same closed-loop steps with the whole batch as one slice, after the timed region")
             except Exception as e:      # never lose the headline line to an auxiliary measurement
                 out["roofline"]["single_slice"] = {"error": repr(e)}
             try:
-                if args.workload == "closed_loop":
+                if args.workload == "closed_loop" and headline:
+                    # round 2's headline regime as a labelled secondary figure: the same loop from the state scaled to 0.3 of its distance from hover,
+                    # closed-loop steps 1..5 timed after step 0 (what profiles/r02/bench_line.json timed)
+                    sec = ClosedLoopSlices(m, N, seeds, args.slices, 6, local_rank, tune)
+                    sec.setup(x0_of(X0_SCALE_SECONDARY), 1)
+                    sec.run(1, collect_stats=False)
+                    torch.cuda.synchronize()
+                    sec.kernel_timing()
+                    t1 = time.perf_counter()
+                    sec.run(5, collect_stats=False)
+                    torch.cuda.synchronize()
+                    dts = (time.perf_counter() - t1) / 5
+                    sec.kernel_timing()
+                    qs_sec = sec.qp_solves
+                    sec.close()
+                    out["secondary"] = {"workload": f"round-2 headline regime: the same closed loop from hover + {X0_SCALE_SECONDARY} (script x0 - hover), closed-loop steps 1..5 "
+                                                    "(few active bounds, no interior point)", "ms_per_step": 1e3 * dts, "qp_solves_per_s": qs_sec / (5 * dts), "steps": 5,
+                                        "slices": args.slices}
+            except Exception as e:
+                out["secondary"] = {"error": repr(e)}
+            if args.secondary_synthetic:
+                try:
                     syn, _ = make_synth(args.slices, 1234)
                     syn.run(1)
                     torch.cuda.synchronize()
@@ -463,18 +575,18 @@ def main():
                     dts = (time.perf_counter() - t1) / 3
                     sst = syn.get("status", (), np.int32)
                     syn.close()
-                    out["secondary"] = {"workload": "round-1 headline: synthetic instances (0-8 active inequalities of 874), update_dynamics + update_linear_cost + solve, "
-                                                    "no linearisation, QP#1 cold every step", "ms_per_step": 1e3 * dts, "qp_solves_per_s": 2 * B / dts,
-                                        "certified_frac": float(np.mean(sst == 0)), "steps": 3, "slices": args.slices}
-            except Exception as e:
-                out["secondary"] = {"error": repr(e)}
-        if cpu_data is not None:
+                    out["secondary_synthetic"] = {"workload": "round-1 headline: synthetic instances (0-8 active inequalities of 874), update_dynamics + update_linear_cost + solve, "
+                                                              "no linearisation, QP#1 cold every step", "ms_per_step": 1e3 * dts, "qp_solves_per_s": 2 * B / dts,
+                                                  "certified_frac": float(np.mean(sst == 0)), "steps": 3, "slices": args.slices}
+                except Exception as e:
+                    out["secondary_synthetic"] = {"error": repr(e)}
+        if cpu_data is not None and cpu_data["A"].shape[0] > 0:
             try:
-                out["cpu_baseline"] = cpu_baseline(m, N, cpu_data)
+                out["cpu_baseline"] = cpu_baseline(m, N, cpu_data, cpu_sample, args.cpu_budget)
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
         else:
-            out["cpu_baseline"] = None
+            out["cpu_baseline"] = {"error": cpu_sample} if cpu_sample else None
         print(json.dumps(out))
     else:
         dev.close()

@@ -180,16 +180,22 @@ int slsqp_qp_solve(slsqp_handle *h, double *x, double *y, int *status, int *iter
 int slsqp_sweep(slsqp_handle *h, const double *eta, const double *eta_f, double *K, double *beta, double *beta_f,
                 double *backoff, double *backoff_f, int loc);
 
+/* Both timing queries take the LENGTH of the caller's buffer and refuse (return < 0, nothing written) a buffer shorter than what they
+   write: SLSQP_TIMING_LEN / SLSQP_KERNEL_TIMING_LEN doubles.  (Round 2 took bare pointers; a caller that still sized its buffer for four
+   values when a fifth was added corrupted its own heap.)  Longer buffers are fine: only the first SLSQP_*_LEN entries are written. */
+#define SLSQP_TIMING_LEN 5
+#define SLSQP_KERNEL_TIMING_LEN 8
 /* elapsed GPU time (ms) of the kernels launched by the last slsqp_solve / slsqp_qp_solve / slsqp_sweep / slsqp_cl_step call,
-   measured with HIP events on the handle's stream: [0] total, [1] QP kernel(s), [2] sweep kernel, [3] other,
-   [4] linearisation of the last slsqp_cl_step (the reference's t_jac, SCP_SLS_jit.py:268,339-341).  ms5 must hold 5 doubles. */
-int slsqp_last_timing(slsqp_handle *h, double *ms5);
+   measured with HIP events on the handle's stream: [0] total, [1] QP kernel (k_qp_solve), [2] sweep kernels, [3] other,
+   [4] linearisation of the last slsqp_cl_step (the reference's t_jac, SCP_SLS_jit.py:268,339-341). */
+int slsqp_last_timing(slsqp_handle *h, double *ms, int len);
 /* accumulated since the last call (opts.time_kernels = 1 for [0], [1]): [0] total ms of the launches of the dominant QP kernel (k_qp_solve: one
-   launch per QP solve; with the tick kernels: k_ne_fwd) from HIP events around each launch on the handle's stream, [1] number of those launches,
-   [2] instances re-solved in fp64 after a mixed-precision attempt, and device counters of the work done: [3] instance forward sweeps (= backward
-   sweeps), [4] how many of them factorised, [5] stages factorised (a factorising sweep of an active-set round re-does only the stages from the
-   first changed one on), [6] QP solves (instances x launches of k_qp_solve), [7] reserved; resets the accumulators.  out must hold 8 doubles. */
-int slsqp_kernel_timing(slsqp_handle *h, double *out8);
+   launch per QP solve) from HIP events around each launch on the handle's stream, [1] number of those launches, [2] instances re-solved in fp64
+   after a mixed-precision attempt, and device counters of the work done: [3] instance forward sweeps, [4] how many of them factorised,
+   [5] stages factorised (a factorising sweep of an active-set round re-does only the stages from the first changed one on), [6] QP solves that
+   ran at least one block solve, [7] block solves that ended after their forward sweep (residual check of an already certified solve: no
+   backward sweep); resets the accumulators. */
+int slsqp_kernel_timing(slsqp_handle *h, double *out, int len);
 void *slsqp_stream(slsqp_handle *h); /* hipStream_t, for callers that share device buffers */
 /* Diagnostic: one wavefront runs one of the wave-level building blocks of the kernels (csrc/wave_la.hpp: the MFMA block products, the fused
    product pair of the SLS propagation, the Gauss-Jordan SPD inverse, the D_k assembly) on packed row-major host operands; (nx,nu) = (17,4)

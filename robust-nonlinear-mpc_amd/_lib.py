@@ -6,6 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("SLSQP_SO") or os.path.join(_HERE, "csrc", "libslsqp_hip.so")   # SLSQP_SO: experiment builds only
 HOST, DEVICE = 0, 1
+TIMING_LEN, KERNEL_TIMING_LEN = 5, 8      # SLSQP_TIMING_LEN / SLSQP_KERNEL_TIMING_LEN of include/slsqp.h
 
 
 class Dims(C.Structure):
@@ -67,8 +68,8 @@ def load():
     lib.slsqp_qp_update_data_vec.argtypes = [vp, dp, dp, dp, C.c_int]
     lib.slsqp_qp_solve.argtypes = [vp, dp, dp, ip, ip, C.c_int, C.POINTER(Opts)]
     lib.slsqp_sweep.argtypes = [vp] + [dp] * 7 + [C.c_int]
-    lib.slsqp_last_timing.argtypes = [vp, dp]
-    lib.slsqp_kernel_timing.argtypes = [vp, dp]
+    lib.slsqp_last_timing.argtypes = [vp, dp, C.c_int]
+    lib.slsqp_kernel_timing.argtypes = [vp, dp, C.c_int]
     lib.slsqp_set_model.argtypes = [vp, C.c_int, dp]
     lib.slsqp_set_E.argtypes = [vp, dp, C.c_int]
     lib.slsqp_linearize.argtypes = [vp, dp, dp, C.c_int]

@@ -70,11 +70,11 @@ struct slsqp_handle {
     bool general_G;             // G, Gf are not [I;-I]: only the sweep-level boundary (slsqp_sweep) is available
     double *Gd, *Gfd;           // device copies of G (ni, nx+nu) and Gf (ni_f, nx) when general_G
     hipEvent_t ev[10];
-    std::vector<hipEvent_t> kev;   // event pairs around every k_ne_fwd launch of the last QP solve (only with opts.time_kernels)
+    std::vector<hipEvent_t> kev;   // event pairs around every k_qp_solve launch since the last harvest (only with opts.time_kernels)
     int n_kev; bool time_kernels;
     double t_total, t_qp, t_sweep, t_fwd; int n_fwd; double fwd_inst;   // fwd_inst: sum over launches of instances that did work
     std::map<std::string, std::pair<void *, size_t>> named;  // name -> (device ptr, bytes per instance)
-    unsigned long long *inst_launches;                       // device counter: instance-sweeps done by k_ne_fwd (roofline accounting)
+    unsigned long long *inst_launches;                       // device counters of k_qp_solve's work (QpArgs::inst_launches; roofline accounting)
     double *ct_part, *cost_tube;                             // sweep's per-column parts of cost_tube^2 and the result
     std::vector<void *> owned, log_owned;                    // device buffers of the handle / of its closed-loop log
     int log_steps;                                           // device-side closed-loop log (slsqp_cl_log): capacity in MPC steps, 0 = off
@@ -712,12 +712,14 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
 
 extern "C" int slsqp_solve(slsqp_handle *h, const double *x0, int loc, const slsqp_opts *opts) { return solve_impl(h, x0, loc, opts, nullptr); }
 
-extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms5) {
+extern "C" int slsqp_last_timing(slsqp_handle *h, double *ms5, int len) {
+    if (!ms5 || len < SLSQP_TIMING_LEN) return fail("slsqp_last_timing: the buffer must hold SLSQP_TIMING_LEN (5) doubles");
     if (h->tl_n > 0) { hipSetDevice(h->dev); hipStreamSynchronize(h->st); tl_take(h); }
     ms5[0] = h->t_total; ms5[1] = h->t_qp; ms5[2] = h->t_sweep; ms5[3] = h->t_total - h->t_qp - h->t_sweep; ms5[4] = h->t_jac;
     return 0;
 }
-extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out8) {
+extern "C" int slsqp_kernel_timing(slsqp_handle *h, double *out8, int len) {
+    if (!out8 || len < SLSQP_KERNEL_TIMING_LEN) return fail("slsqp_kernel_timing: the buffer must hold SLSQP_KERNEL_TIMING_LEN (8) doubles");
     unsigned long long il[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipSetDevice(h->dev);
     hipMemcpyAsync(il, h->inst_launches, sizeof(il), hipMemcpyDeviceToHost, h->st);

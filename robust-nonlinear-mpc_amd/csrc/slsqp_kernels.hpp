@@ -49,7 +49,7 @@ struct Lay {
 };
 
 // ------------------------------------------------------------------------------------------------
-// QP kernel: primal-dual interior point on the block-tridiagonal normal equations + active-set polish
+// QP kernel: active-set iteration on the block-tridiagonal normal equations first, primal-dual interior point as the fall-back
 // ------------------------------------------------------------------------------------------------
 struct QpArgs {
     int B, N;

@@ -199,15 +199,15 @@ class BatchedFastSLS:
         return out
 
     def timing_ms(self):
-        t = np.zeros(5)
-        self.lib.slsqp_last_timing(self.h, _ptr(t))
+        t = np.zeros(L.TIMING_LEN)
+        L.check(self.lib.slsqp_last_timing(self.h, _ptr(t), t.size))
         return dict(total=t[0], qp=t[1], sweep=t[2], other=t[3], jac=t[4])
 
     def kernel_timing(self):
         """(total ms, launches) of the dominant QP kernel since the last call (HIP events on the handle's stream; needs opts.time_kernels = 1);
         the device counters of the work those launches did land in attributes."""
-        t = np.zeros(8)
-        self.lib.slsqp_kernel_timing(self.h, _ptr(t))
+        t = np.zeros(L.KERNEL_TIMING_LEN)
+        L.check(self.lib.slsqp_kernel_timing(self.h, _ptr(t), t.size))
         self.mx_retries = int(t[2])            # instances re-solved in fp64 after a mixed-precision attempt (opts.precision = 1)
         self.fwd_instance_sweeps = int(t[3])   # instance forward sweeps (= backward sweeps)
         self.fwd_factor_sweeps = int(t[4])     # ... of which factorising
@@ -360,8 +360,8 @@ class SlicedDeviceBatch:
 
     MPC instances are independent, so the slices need not advance in lockstep: `run(steps)` lets every slice do its `steps` MPC
     steps back to back on its own thread, and the few-instance tails of one slice's QP solves (latency-bound launches that leave
-    the GPU almost idle) overlap the bulk launches of the others.  Measured on MI355X, rocket N=20, 4096 instances: 19.5 ms per step
-    with one slice, 18.0 with two, 17.6 with three, 22.6 with four (scripts/bench_two_streams.py).  The C-ABI calls release the GIL."""
+    the GPU almost idle) overlap the bulk launches of the others (DESIGN.md section 6 holds the measured slice counts).  The C-ABI
+    calls release the GIL."""
 
     KEYS = ("A", "B", "g", "gN", "c", "q", "x0_arg")
 
@@ -417,7 +417,7 @@ class SlicedDeviceBatch:
         return np.concatenate([f.get(name, shape, dtype) for f in self.solvers], axis=0)
 
     def kernel_timing(self):
-        """Summed over the slices: (total ms of k_ne_fwd launches, launches, instance sweeps, fp64 re-solves)."""
+        """Summed over the slices: (total ms of k_qp_solve launches, launches, instance sweeps, fp64 re-solves)."""
         tot = [0.0, 0, 0, 0]
         self.fwd_factor_sweeps = self.factor_stages = self.qp_solves = 0
         for f in self.solvers:

@@ -89,6 +89,6 @@ def solve():
     rc = lib.slsqp_qp_solve(_state["h"], _p(x), _p(y), C.byref(st), C.byref(it), L.HOST, C.byref(_state["opts"]))
     if rc:
         raise RuntimeError("slsqp_qp_solve: " + lib.slsqp_last_error().decode())
-    ms = (C.c_double * 5)()      # total, qp, sweep, other, jac (slsqp_last_timing writes five values)
-    lib.slsqp_last_timing(_state["h"], ms)
+    ms = (C.c_double * L.TIMING_LEN)()      # total, qp, sweep, other, jac; the library refuses a shorter buffer
+    L.check(lib.slsqp_last_timing(_state["h"], ms, L.TIMING_LEN))
     return x, y, (0 if st.value in (0, 4) else st.value), it.value, ms[1] * 1e-3

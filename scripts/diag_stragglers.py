@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
 m = get_model("rocket")
-B, N, steps = 1024, 20, int(sys.argv[2]) if len(sys.argv) > 2 else 30
+B, N, steps = (int(sys.argv[3]) if len(sys.argv) > 3 else 1024), 20, int(sys.argv[2]) if len(sys.argv) > 2 else 30
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 x0 = m.x_ref + scale * (m.extra["x0"] - m.x_ref)
 W = np.stack([disturbance_stream(s, steps, m.nx) for s in range(B)], axis=1)
@@ -21,5 +21,6 @@ for i in range(steps):
         big = ran & (tk > 40)
         line += (f" | QP{slot+1} ran {ran.mean():.2f} status(0,1,3,4) {[(st[ran] == v).sum() for v in (0, 1, 3, 4)]} ticks mean {tk[ran].mean() if ran.any() else 0:.1f} max {tk.max()}"
                  f" >40 ticks: {big.sum()} (status {np.bincount(st[big], minlength=5).tolist() if big.any() else []}, its max {its[big].max() if big.any() else 0})")
-    print(line, flush=True)
+    t = cl.f.timing_ms()
+    print(line + f" | gpu ms: total {t['total']:.2f} qp {t['qp']:.2f} sweep {t['sweep']:.2f} jac {t['jac']:.2f}", flush=True)
 cl.close()

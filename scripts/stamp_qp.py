@@ -7,11 +7,12 @@ import numpy as np
 from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
 m = get_model("rocket")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-N, steps = 20, 4
-x0 = m.x_ref + 0.3 * (m.extra["x0"] - m.x_ref)
+scale = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
+N, steps = 20, int(sys.argv[3]) if len(sys.argv) > 3 else 4
+x0 = m.x_ref + scale * (m.extra["x0"] - m.x_ref)
 W = np.stack([disturbance_stream(s, steps, m.nx) for s in range(B)], axis=1)
 cl = ClosedLoopMPC(m, N, B)
-cl.reset(np.tile(x0, (B, 1)), solve_nominal=True)
+cl.reset(np.tile(x0, (B, 1)), solve_nominal=True, continuation=2 if scale > 0.6 else 1)
 for i in range(steps):
     cl.step(W[i], fetch=False)
     kk = cl.f.get("kkt", (8,)); qs = cl.f.get("qp_stats", (2, 8), np.int32)

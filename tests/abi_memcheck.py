@@ -18,6 +18,12 @@ f.update_linear_cost(batch["q"])
 f.opts.time_kernels = 1
 out = f.solve(batch["x0_arg"])
 f.timing_ms(); f.kernel_timing()
+# the timing queries take the buffer's length and refuse a short one (nothing written) instead of overrunning it
+import ctypes as C
+short = (C.c_double * 8)(*([-7.0] * 8))
+assert f.lib.slsqp_last_timing(f.h, short, 4) != 0 and b"SLSQP_TIMING_LEN" in f.lib.slsqp_last_error() and list(short) == [-7.0] * 8
+assert f.lib.slsqp_kernel_timing(f.h, short, 7) != 0 and b"SLSQP_KERNEL_TIMING_LEN" in f.lib.slsqp_last_error() and list(short) == [-7.0] * 8
+assert f.lib.slsqp_last_timing(f.h, short, 8) == 0 and short[5] == -7.0      # a longer buffer is fine: five values written
 for name, shape, dt in (("eta", (N, N, m.ni), np.float64), ("eta_f", (N + 1, m.ni_f), np.float64), ("K", (N, N + 1, m.nu, m.nx), np.float64), ("kkt", (8,), np.float64),
                         ("qp_stats", (2, 8), np.int32), ("status", (), np.int32), ("pin_dual", (m.nx,), np.float64), ("ubg", (f.mb,), np.float64)):
     f.get(name, shape, dt)

@@ -640,17 +640,136 @@ def test_script_rocket_x0_runs_closed_loop_from_the_gpu_initialiser():
         assert compared >= 1, ref["oracle_qp_converged"]
 
 
+def _script_regime_run(m, N, seeds, steps, check_kkt):
+    """Closed loop of the rocket script (its own x0, weights, rti = 1 / one fast-SLS step, 30 steps, seed s = the stream of np.random.seed(s)) for
+    `seeds`, step by step; returns per-step arrays and, with check_kkt, the independent KKT residuals (oracle/sls_oracle.c so_qp_kkt) of every
+    final QP the GPU reports solved."""
+    from oracle import oracle as O
+    from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream
+    B = len(seeds)
+    W = np.stack([disturbance_stream(s, steps, m.nx) for s in seeds], axis=1)
+    cl = ClosedLoopMPC(m, N, B)
+    cl.reset(np.tile(m.extra["x0"], (B, 1)), solve_nominal=True, continuation=2)
+    assert (cl.nlp_status == 0).all()
+    f = cl.f
+    n, mb = f.n, f.mb
+    d = O.dims_of(m.nx, m.nu, m.nw, N, m.ni, m.ni_f)
+    rec = dict(success=[], qp_stats=[], x=[], u0=[], nominal_x=[], kkt_worst=0.0, kkt_checked=0)
+    for i in range(steps):
+        cl.step(W[i], fetch=False)
+        qs = f.get("qp_stats", (2, 8), np.int32)
+        rec["success"].append(f.get("scp_success", (), np.int32).astype(bool)); rec["qp_stats"].append(qs)
+        rec["x"].append(f.get("x_meas", (m.nx,))); rec["u0"].append(f.get("u0", (m.nu,))); rec["nominal_x"].append(f.get("nominal_x", (N + 1, m.nx)))
+        if check_kkt:
+            A, Bm, q = f.get("A", (N, m.nx, m.nx)), f.get("Bm", (N, m.nx, m.nu)), f.get("q", (n,))
+            ub, lb, x0a = f.get("ubg", (mb,)), f.get("lbg", (mb,)), f.get("x0_arg", (m.nx,))
+            pv, dv, pin, st = f.get("primal_vec", (n,)), f.get("dual_vec", (mb,)), f.get("pin_dual", (m.nx,)), f.get("status", (), np.int32)
+            for b in np.flatnonzero((qs[:, 1, 6] == 0) & (st == 0)):      # the tightened QP (the one whose primal is applied) ended certified
+                l = np.concatenate([np.maximum(lb[b], -1e20), -x0a[b] - 1e-10]); u = np.concatenate([ub[b], -x0a[b] + 1e-10])
+                k = O.qp_kkt(d, A[b], Bm[b], m.G, m.Gf, m.Q, m.R, m.Qf, q[b], l, u, pv[b], np.concatenate([dv[b], pin[b]]))
+                scale = max(1.0, np.abs(q[b]).max())
+                worst = max(k["stationarity"] / scale, k["primal"], k["dual_sign"], k["complementarity"] / scale)
+                rec["kkt_worst"] = max(rec["kkt_worst"], worst); rec["kkt_checked"] += 1
+    cl.close()
+    return {k: (np.stack(v) if isinstance(v, list) else v) for k, v in rec.items()}
+
+
+def test_script_regime_64_seeds_30_steps_every_qp_certified_or_flagged():
+    """The reference script's own regime as a tested configuration (expe/main_rocket_robust_closed_loop.py:110-128, 149-182): script x0, N = 20,
+    64 disturbance seeds x all 30 closed-loop steps.  Every QP is either certified (status 0; the tightened QP's certificate re-computed on the CPU
+    by the oracle's independent KKT routine), flagged infeasible at x0 before any work (status 2), skipped because the step had failed (-1), or
+    flagged unsolved (1 / 3) -- the last within the fraction bench.py reports for this regime; the rerun is bit-identical."""
+    from robust_nonlinear_mpc_amd import get_model
+    m = get_model("rocket")
+    N, S, steps = 20, 64, 30
+    r1 = _script_regime_run(m, N, np.arange(S), steps, check_kkt=True)
+    r2 = _script_regime_run(m, N, np.arange(S), steps, check_kkt=False)
+    for k in ("x", "u0", "nominal_x", "success", "qp_stats"):
+        assert np.array_equal(r1[k], r2[k]), k
+    st = r1["qp_stats"][..., 6]                                    # (steps, S, 2)
+    assert np.isin(st, (-1, 0, 1, 2, 3, 4)).all()
+    ran = (st != -1) & (st != 2)
+    unsolved = ran & ~np.isin(st, (0, 4))
+    # bench.py's 30-step line of this regime (profiles/r03): <= 0.3 % of the QPs that ran end unsolved (infeasible tightened QPs whose x0 is inside
+    # its box); 64 x 30 x 2 = 3840 QPs here, so allow a handful
+    assert unsolved.sum() <= max(4, 0.005 * ran.sum()), (int(unsolved.sum()), int(ran.sum()))
+    assert (st[ran] != 4).mean() > 0.99                             # solved means certified, not merely interior-point accurate
+    assert ran[:, :, 0].mean() > 0.85 and r1["success"].mean() > 0.7, (ran[:, :, 0].mean(), r1["success"].mean())
+    assert r1["kkt_checked"] > 0.6 * S * steps and r1["kkt_worst"] < 1e-7, (r1["kkt_checked"], r1["kkt_worst"])
+    assert np.isfinite(r1["x"]).all() and len({r1["x"][-1, s].tobytes() for s in range(S)}) == S      # seeds differ
+
+
+def test_script_regime_2_seeds_30_steps_vs_cpu_restatement():
+    """Seeds 0 (the script's own disturbance stream) and 1, script x0, N = 20, all 30 closed-loop steps against the CPU restatement of the closed
+    loop started from the SAME first nominal (the role IPOPT's has in the script), QPs by the dense interior point (tests/ref_ipm.py): measured
+    states, applied inputs and nominal trajectories to 1e-6, step by step, success flags equal."""
+    from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
+    from problems import run_oracle_closed_loop
+    m = get_model("rocket")
+    N, B, steps = 20, 2, 30
+    x0 = np.tile(m.extra["x0"], (B, 1))
+    W = np.stack([disturbance_stream(s, steps, m.nx) for s in range(B)], axis=1)
+    cl = ClosedLoopMPC(m, N, B)
+    cl.reset(x0, solve_nominal=True, continuation=2)
+    assert (cl.nlp_status == 0).all()
+    X, U = cl.f.get("nominal_x", (N + 1, m.nx)), cl.f.get("nominal_u", (N, m.nu))
+    out = [cl.step(W[i]) for i in range(steps)]
+    cl.close()
+    for b in range(B):
+        ref = run_oracle_closed_loop(m, N, x0[b], steps, m.rti, m.fast_sls_rti_steps, W[:, b], X_nom=X[b], U_nom=U[b], qp_backend="ipm")
+        assert [bool(o["success"][b]) for o in out] == [bool(v) for v in ref["success"]], b
+        sx, su = max(1.0, np.abs(ref["nominal_x"]).max()), max(1.0, np.abs(ref["nominal_u"]).max())
+        for i in range(steps):
+            assert np.max(np.abs(out[i]["nominal_x"][b] - ref["nominal_x"][i])) < 1e-6 * sx, (b, i)
+            assert np.max(np.abs(out[i]["nominal_u"][b] - ref["nominal_u"][i])) < 1e-6 * su, (b, i)
+            assert np.max(np.abs(out[i]["u0"][b] - ref["u0"][i])) < 1e-6 * su, (b, i)
+            if ref["backoff_x"][i] is not None:
+                assert np.allclose(out[i]["backoff_x"][b], ref["backoff_x"][i], rtol=1e-4, atol=1e-8), (b, i)
+        assert sum(ref["success"]) >= 20, ref["success"]
+
+
+@pytest.mark.parametrize("model,N", [("pendulum", 10), ("quadrotor", 20)])
+def test_script_length_closed_loops_vs_oracle(model, N):
+    """The pendulum script's 60 steps from its own x0 (expe/main_pendulum_robust_closed_loop.py:60, 96; rti = 3, two fast-SLS steps, no noise) and the
+    quadrotor script's 30 steps (main_quadrotor...:92; its unseeded random x0 drawn here from a seeded generator by the milder recipe of
+    test_closed_loop_vs_oracle) at full length, one instance, against the CPU restatement of the closed loop."""
+    from robust_nonlinear_mpc_amd import ClosedLoopMPC, get_model
+    from problems import run_oracle_closed_loop
+    m = get_model(model)
+    steps = m.extra["sim_steps"]
+    if model == "pendulum":
+        x0 = m.extra["x0"][None]
+    else:
+        rng = np.random.default_rng(3)
+        D = np.array([2.0] * 3 + [1.0] * 3 + [0.0] + [0.1] * 3 + [0.5] * 3)
+        x0 = (m.x_ref + D * rng.uniform(-1, 1, m.nx))[None]
+        x0[:, 6:10] /= np.linalg.norm(x0[:, 6:10], axis=1, keepdims=True)
+    cl = ClosedLoopMPC(m, N, 1)
+    out = cl.run_on_device(x0, steps, None)
+    cl.close()
+    ref = run_oracle_closed_loop(m, N, x0[0], steps, m.rti, m.fast_sls_rti_steps, None)
+    if not all(ref["oracle_qp_converged"]):          # the ADMM restatement gave up on a QP: the dense interior point as the oracle's QP back end
+        ref = run_oracle_closed_loop(m, N, x0[0], steps, m.rti, m.fast_sls_rti_steps, None, qp_backend="ipm")
+    assert list(out["success"][0]) == list(ref["success"]) and all(ref["success"])
+    scale = max(1.0, np.abs(ref["nominal_x"]).max())
+    assert np.max(np.abs(out["state_trajectory"][0].T - ref["state"])) < 1e-6 * scale
+    assert np.max(np.abs(out["input_trajectory"][0].T - ref["u0"][: steps - 1])) < 1e-6 * max(1.0, np.abs(ref["u0"]).max())
+    assert np.max(np.abs(out["nominal_trajectory_x"][0].transpose(2, 1, 0) - ref["nominal_x"])) < 1e-6 * scale
+    # the loop regulates: the last state is much closer to the reference point than the first
+    assert np.linalg.norm(ref["state"][-1] - m.x_ref) < 0.2 * np.linalg.norm(ref["state"][0] - m.x_ref)
+
+
 def test_config5_shaped_monte_carlo_1024_seeds_30_steps():
     """BASELINE config 5 at its per-GPU size: 1024 disturbance seeds x 30 closed-loop steps of the rocket (N = 20, script weights, rti = 1, one fast-SLS
-    step; x0 = the script's initial state scaled to 0.3 of its distance from hover so that the roll-out initialiser applies).  Properties at full size:
+    step) from the SCRIPT'S OWN initial state (main_rocket...:110-126; nominal by the GPU initialiser's two-stage continuation).  Properties at full size:
     the rerun is bit-identical, seed 0 follows the reference script's own disturbance stream (tests/golden/rocket_noise_seed0.npz: np.random.seed(0),
     w = 2 rand(17) - 1 per step, main_rocket...:30,180), every step of every run is either solved or flagged, solved steps stay inside the box."""
     from robust_nonlinear_mpc_amd import disturbance_stream, get_model, run_monte_carlo
     m = get_model("rocket")
     S, steps, N = 1024, 30, 20
-    x0 = m.x_ref + 0.3 * (m.extra["x0"] - m.x_ref)
-    r1 = run_monte_carlo(m, N, np.arange(S), steps, x0, slices=3, solve_nominal=True)
-    r2 = run_monte_carlo(m, N, np.arange(S), steps, x0, slices=3, solve_nominal=True)
+    x0 = m.extra["x0"]
+    r1 = run_monte_carlo(m, N, np.arange(S), steps, x0, slices=3, solve_nominal=True, continuation=2)
+    r2 = run_monte_carlo(m, N, np.arange(S), steps, x0, slices=3, solve_nominal=True, continuation=2)
     for k in ("state_trajectory", "input_trajectory", "nominal_trajectory_x", "backoff_trajectory_x", "success", "primal_infeasibility"):
         assert np.array_equal(r1[k], r2[k], equal_nan=True), k
     Wg = np.load(os.path.join(GOLDEN, "rocket_noise_seed0.npz"))["W"]
@@ -661,12 +780,13 @@ def test_config5_shaped_monte_carlo_1024_seeds_30_steps():
     X, U = r1["state_trajectory"][0], r1["input_trajectory"][0]           # (nx, steps), (nu, steps-1)
     succ = r1["success"]
     pairs = [t for t in range(steps - 1) if succ[0, t] and succ[0, t + 1]]
-    assert len(pairs) >= 10, succ[0]
+    assert len(pairs) >= 5, succ[0]
     for t in pairs:
         assert np.allclose(X[:, t + 1], host_ddyn(m.model_id, X[:, t], U[:, t]) + m.E @ Wg[t], rtol=0, atol=1e-9)
     # a step is flagged, not solved, when the noise sample (|w|inf <= 1, i.e. |w|2 up to sqrt(17)) carries the measured state past the bound the
-    # 2-norm tube was sized for: ~2 % of the steps in the first second of the manoeuvre; the reference script would carry on the same way (:149-182)
-    assert succ.shape == (S, steps) and succ.mean() > 0.95, succ.mean()
+    # 2-norm tube was sized for (from the script's x0 the nominal rides the omega_x and v_z bounds: ~10 % of the steps, more towards the end of the
+    # manoeuvre); the reference script would carry on the same way (:149-182)
+    assert succ.shape == (S, steps) and succ.mean() > 0.7, succ.mean()
     assert np.isfinite(r1["state_trajectory"]).all()
     nx_ok = r1["nominal_trajectory_x"].transpose(0, 3, 2, 1)[succ]           # (runs x steps solved, N+1, nx)
     assert (nx_ok[:, 1:] <= m.x_ub + 1e-6).all() and (nx_ok[:, 1:] >= m.x_lb - 1e-6).all()

@@ -229,6 +229,112 @@ def test_run_monte_carlo_gather_branch_world_size_2_gloo():
         assert t_qp.max() == 3.0                                                           # slices run concurrently: max over the 3 + 3 (or 2 + 3) split
 
 
+class _FakeSolver:
+    """What bench.py touches on ClosedLoopMPC.f, without a GPU."""
+    def __init__(self, B, nx, nu):
+        self.B, self.nx, self.nu = B, nx, nu
+        self.fwd_instance_sweeps = self.bwd_sweeps_skipped = self.mx_retries = self.fwd_factor_sweeps = self.factor_stages = self.qp_solves = 0
+
+    def kernel_timing(self):
+        self.fwd_instance_sweeps, self.factor_stages, self.fwd_factor_sweeps = self.pending * 6, self.pending * 40, self.pending * 2
+        self.qp_solves, self.pending = self.pending, 0
+        return 1.0, 2
+
+
+class _FakeSlices:
+    """Stand-in for bench.ClosedLoopSlices: every step "solves" both QPs of every instance; x_meas encodes the seed so the gather can be checked."""
+    instances = []
+
+    def __init__(self, m, N, seeds, n_slices, steps_total, device, tune):
+        import types
+        self.m, self.seeds = m, np.asarray(seeds)
+        B = len(seeds)
+        K = max(1, min(int(n_slices), B))
+        self.bounds = [(B * k // K, B * (k + 1) // K) for k in range(K)]
+        self.cl = [types.SimpleNamespace(f=_FakeSolver(hi - lo, m.nx, m.nu), B=hi - lo) for lo, hi in self.bounds]
+        for c in self.cl:
+            c.f.pending = 0
+        self.stats, self.step_ms = [[] for _ in self.cl], [[] for _ in self.cl]
+        _FakeSlices.instances.append(self)
+
+    def setup(self, x0, continuation=1):
+        return np.zeros(len(self.seeds), dtype=np.int32)
+
+    def run(self, steps, collect_stats=True):
+        for k, c in enumerate(self.cl):
+            for _ in range(steps):
+                c.f.pending += 2 * c.B
+                self.step_ms[k].append(1.0)
+                if collect_stats:
+                    st = np.zeros((c.B, 2, 8), dtype=np.int32); st[..., 1] = 3
+                    self.stats[k].append(st)
+        return [dict(jac=0.1 * steps, qp=0.5 * steps, sweep=0.2 * steps, total=1.0 * steps) for _ in self.cl]
+
+    def fetch_device(self, name, shape):
+        import torch
+        return torch.from_numpy(np.tile(self.seeds[:, None].astype(float), (1,) + tuple(shape)))
+
+    def get(self, name, shape, dtype=None):
+        return np.ones((len(self.seeds),) + tuple(shape), dtype=dtype or np.float64) if name == "scp_success" else np.zeros((len(self.seeds),) + tuple(shape), dtype=dtype or np.float64)
+
+    def kernel_timing(self):
+        tot = [0.0, 0, 0, 0]
+        self.fwd_factor_sweeps = self.factor_stages = self.qp_solves = 0
+        for c in self.cl:
+            ms, n = c.f.kernel_timing()
+            tot[0] += ms; tot[1] += n; tot[2] += c.f.fwd_instance_sweeps
+            self.factor_stages += c.f.factor_stages; self.qp_solves += c.f.qp_solves
+        return tuple(tot)
+
+    def close(self):
+        pass
+
+
+def _bench_gloo_worker(rank, world, port, q):
+    import io, contextlib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import bench
+    torch.cuda.set_device = lambda d: None                       # no GPU here: bench.py's own rank / reduce / gather / JSON logic runs, the slice is a stand-in
+    torch.cuda.synchronize = lambda *a: None
+    bench.ClosedLoopSlices = _FakeSlices
+    gathered = []
+    real_gather = bench.gather_results
+    bench.gather_results = lambda t, w, b: gathered.append(real_gather(t, w, b)) or gathered[-1]
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "8", "--backend", "gloo", "--no-cpu", "--no-secondary", "--model", "rocket"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    q.put((rank, buf.getvalue(), [[t.numpy().copy() for t in g] for g in gathered]))
+
+
+def test_bench_multi_rank_path_world_size_2_gloo():
+    """bench.py's own N > 1 path end to end on two gloo ranks (the GPU slice replaced by a stand-in): rank r owns seeds [r B, (r+1) B), the warm-up
+    batch is disjoint from both, value = QP solves of ALL ranks over the slowest rank's time, the one all-gather carries every rank's rows, and only
+    rank 0 prints the JSON line (n_gpus 2, weak scaling)."""
+    import json
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_bench_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=240) for _ in ps], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    assert res[1][1].strip() == ""                                             # rank 1 prints nothing
+    line = json.loads(res[0][1].strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert line["config"]["qp_solves_counted"] == 2 * 8 * 3 * 2                 # 2 QPs x 8 instances x 3 steps x 2 ranks (the warm-up batch is not counted)
+    assert line["config"]["qp_solves_nominal"] == 96 and abs(line["value"] * line["ms_per_step"] * 3e-3 - 96) < 1e-6
+    assert "closed-loop steps 0..2" in line["config"]["workload"] and "disjoint seed batch" in line["config"]["workload"]
+    assert line["roofline"]["traffic"] is None and line["cpu_baseline"] is None
+    for rank, _, gathered in res:
+        warm, timed = gathered[0], gathered[-1]
+        assert len(timed) == 2 and np.array_equal(timed[0][:, 0], np.arange(8.0)) and np.array_equal(timed[1][:, 0], 8.0 + np.arange(8.0))
+        assert min(w[:, 0].min() for w in warm) >= (1 << 20)                   # warm-up seeds: disjoint from every rank's own
+
+
 def test_bench_gpus_flag_launches_ranks_or_refuses(monkeypatch):
     """`bench.py --gpus N` without a launcher starts N rank processes itself (torch.distributed.run, 127.0.0.1) before touching the GPU;
     under a launcher with a different WORLD_SIZE it refuses instead of printing a line for the wrong N."""
@@ -317,6 +423,7 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
     for st, names in fields.items():
         src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
         src += [f'  printf("{st}.{n} %zu\\n", offsetof({st}, {n}));' for n in names]
+    src += ['  printf("SLSQP_TIMING_LEN %d\\n", SLSQP_TIMING_LEN);', '  printf("SLSQP_KERNEL_TIMING_LEN %d\\n", SLSQP_KERNEL_TIMING_LEN);']
     src += ['  return 0;', '}']
     cfile = tmp_path / "layout.c"
     cfile.write_text("\n".join(src))
@@ -324,6 +431,8 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(cfile)])
     got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
     assert int(got["slsqp_opts"]) == C.sizeof(L.Opts) and int(got["slsqp_dims"]) == C.sizeof(L.Dims)
+    # buffer lengths of the two timing queries (the library refuses shorter buffers; the mirror sizes its own from these)
+    assert int(got["SLSQP_TIMING_LEN"]) == L.TIMING_LEN and int(got["SLSQP_KERNEL_TIMING_LEN"]) == L.KERNEL_TIMING_LEN
     for cls, st in ((L.Opts, "slsqp_opts"), (L.Dims, "slsqp_dims")):
         for n in fields[st]:
             assert int(got[f"{st}.{n}"]) == getattr(cls, n).offset, (st, n)

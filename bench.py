@@ -232,7 +232,7 @@ def qp_statistics(stats):
         out[name] = {
             **head,
             "solved_frac": float(solved.mean()), "certified_frac": float((st == 0).mean()),
-            "started_warm_frac": float(warm.mean()), "interior_point_frac": float(cold.mean()),
+            "started_warm_frac": float((warm > 0).mean()), "started_from_previous_last_qp_set_frac": float((warm == 2).mean()), "interior_point_frac": float(cold.mean()),
             # how the solve got to its answer: first active-set attempt (warm set, or the empty set on a cold solve) / interior point from scratch /
             # interior point restarted from the first QP's iterate / active set from the empty set after a failed warm attempt
             "path_frac": {"first_attempt": float((fb == 0).mean()), "ipm_cold": float((fb == 1).mean()), "ipm_restart": float((fb == 2).mean()),
@@ -356,7 +356,7 @@ def main():
     def tune(f, synthetic=False):
         if os.environ.get('QP_WARM_ROUNDS'):
             f.opts.warm_rounds = int(os.environ['QP_WARM_ROUNDS'])
-        for k in ('as_first', 'as_rounds', 'as_max_viol', 'ipm_restart', 'as_warm_max_set'):
+        for k in ('as_first', 'as_rounds', 'as_max_viol', 'ipm_restart', 'as_warm_max_set', 'as_warm_last'):
             if os.environ.get('QP_' + k.upper()):
                 setattr(f.opts, k, int(os.environ['QP_' + k.upper()]))
         f.opts.precision = args.precision

@@ -82,8 +82,11 @@ typedef struct {
                             fails restart the interior point from a copy of the first QP's iterate at mu ~ 1e-3 |q|inf instead of from scratch */
     int time_kernels;    /* 0 (default): no per-launch timing.  1: HIP event pairs around every launch of the dominant QP kernel on the
                             handle's stream, read with slsqp_kernel_timing (bench.py's roofline leg) */
-    int as_warm_max_set; /* 28 (default): the last QP of a call skips its warm active-set attempt and starts the interior point when the first QP ended
-                            with more active bounds than this (0 = never skip) */
+    int as_warm_max_set; /* 28 (default): the last QP of a call does not start its warm active-set attempt from the first QP's set when that set has more
+                            active bounds than this (0 = no limit): it starts from the previous call's last set (as_warm_last) or, without one, the interior point */
+    int as_warm_last;    /* 1 (default): where as_warm_max_set rules out the first QP's set (or the first QP left no certified set), the last QP of a call starts
+                            from the certified active set of the PREVIOUS call's last QP, moved one stage with the horizon after slsqp_cl_step's shift;
+                            2: whenever such a set exists; 0: never */
 } slsqp_opts;
 
 void slsqp_default_opts(slsqp_opts *o);

@@ -32,7 +32,7 @@ extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
     o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-6; o->conv_tol = 1e-3;
     o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 20;
-    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0; o->as_first = 2; o->as_rounds = 24; o->as_max_viol = 64; o->ipm_restart = 1; o->as_warm_max_set = 28;
+    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0; o->as_first = 2; o->as_rounds = 24; o->as_max_viol = 64; o->ipm_restart = 1; o->as_warm_max_set = 28; o->as_warm_last = 1;
 }
 
 struct slsqp_handle {
@@ -523,7 +523,7 @@ static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int w
     QpArgs a;
     a.qpstat = h->qpstat; a.stat_slot = stat_slot; a.diag = h->qp_diag;
     static const double snap_mu = getenv("SLSQP_SNAP_MU") ? atof(getenv("SLSQP_SNAP_MU")) : 1e-3;
-    a.snap_take = snap_take; a.snap_use = snap_use && o->ipm_restart; a.snap_mu = snap_mu; a.call_id = h->call_id; a.as_first = o->as_first; a.as_rounds = o->as_rounds; a.as_max_viol = o->as_max_viol; a.as_warm_max_set = o->as_warm_max_set;
+    a.snap_take = snap_take; a.snap_use = snap_use && o->ipm_restart; a.snap_mu = snap_mu; a.call_id = h->call_id; a.as_first = o->as_first; a.as_rounds = o->as_rounds; a.as_max_viol = o->as_max_viol; a.as_warm_max_set = o->as_warm_max_set; a.as_warm_last = o->as_warm_last;
     { static const int ws = getenv("SLSQP_WARM_SHIFT") ? atoi(getenv("SLSQP_WARM_SHIFT")) : 1; a.warm_shift = ws ? warm_shift : 0; }
     a.prox = prox; a.prox_stride = 12; a.inst_launches = h->inst_launches;
     a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;
@@ -700,7 +700,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     }
     // final QP: RTI always (fast_SLS_jit.py:293); converge mode only for instances that hit MAX_ITER (:311)
     const int tl_q2 = tl_begin(h, 0);
-    if (launch_qp(h, h->alive, &o, 1, nullptr, 1, 1, 1)) return -1;
+    if (launch_qp(h, h->alive, &o, 1, nullptr, 1, 1, 1, wshift)) return -1;
     tl_end(h, tl_q2);
     hipLaunchKernelGGL(k_finish, dim3(gb), dim3(256), 0, h->st, B, rti ? 1 : 0, h->alive, h->infeas, h->success, active, h->pending_reset);
     tl_end(h, tl_tot);

@@ -92,6 +92,9 @@ struct QpArgs {
     int as_warm_max_set;      // a QP that follows another one of the same call (tightened bounds) skips the warm attempt and goes straight to the
                               // interior point when the set it would start from has more entries than this (0 = never): from ~30 active bounds a
                               // tightening moves so many of them that the rounds cost more than the interior point
+    int as_warm_last;         // the LAST QP of a call (stat_slot 1: the tightened one) may start from the certified set of the previous call's last QP, moved with
+                              // the horizon like the first QP's (warm_shift): 1 = when the first QP's set is too large for as_warm_max_set (or gave no
+                              // certified set), i.e. where the interior point would run otherwise; 2 = whenever such a set exists; 0 = never
     int as_max_viol;          // an attempt is abandoned when a solve leaves more violated bounds than this, or more than 2 x the previous round's + 8
     int n_refine;             // refinement solves per polish (1 in fp64, 3 with fp32 factorisations)
     double early_ctol;        // tolerance (relative to max(1,|q|inf)) of the look at the un-refined polish solve: its accuracy class
@@ -110,8 +113,9 @@ template <int NX, int NU>
 __host__ __device__ constexpr int qp_lds_doubles(int) { return QpLds<NX, NU>::TOTAL; }
 
 // workspace arrays per instance (doubles): 12 n-vectors + 3 (N*NX)-vectors of the solver, then the copy of an interior-point iterate
-// (6 n-vectors + 1 (N*NX)-vector: z, s_u, s_l, lambda_u, lambda_l, E'nu, nu), then the certified active set of the call's first QP (1 n-vector) and u of the last forward sweep (1 (N*NX)-vector)
-__host__ __device__ inline size_t qp_ws_doubles(int n, int N, int NX) { return (size_t)19 * n + (size_t)5 * N * NX; }
+// (6 n-vectors + 1 (N*NX)-vector: z, s_u, s_l, lambda_u, lambda_l, E'nu, nu), then the certified active set of the call's first QP (1 n-vector), u of the last forward sweep
+// (1 (N*NX)-vector) and the certified active set of the call's last QP (1 n-vector)
+__host__ __device__ inline size_t qp_ws_doubles(int n, int N, int NX) { return (size_t)20 * n + (size_t)5 * N * NX; }
 
 template <int NX, int NU>
 struct NeG {   // global-memory operands of the sweeps (this instance)
@@ -547,6 +551,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
     double *PI = CL + n, *V = PI + n, *G = V + n, *ACT = G + n, *W = ACT + n, *NUA = W + N * NX, *NUP = NUA + N * NX;
     double *SZ = NUP + N * NX, *SSU = SZ + n, *SSL = SSU + n, *SLU = SSL + n, *SLL = SLU + n, *SGC = SLL + n, *SNUA = SGC + n;   // copy of an interior-point iterate
     double *ACT1 = SNUA + N * NX;   // active set the first QP of the previous fast-SLS call ended on (warm start of the next call's first QP)
+    double *ACT2 = ws + 19 * (size_t)n + 5 * (size_t)N * NX;   // ... and the one its last QP ended on (behind UF; warm start of the next call's last QP, QpArgs::as_warm_last)
     Costs cst = a.cst;
     cst.prox = a.prox ? a.prox[(size_t)b * a.prox_stride] : 0.0;
     QpState *stp = (QpState *)a.state + b;
@@ -579,19 +584,28 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         // resemble each other more than a tightened and an un-tightened one: 2.8 against 3.9 rounds, scripts/proto/as_warm_sources.py) -- also
         // when the solve in between did not end on a certificate (e.g. a measured state outside its own box, status 2): ACT1 is only ever
         // written with a certified set
-        const bool from_act1 = a.warm && status == ST_INIT && a.stat_slot == 0 && a.snap_use == 0 && stp->act1_ok != 0.0;
+        const int okbits = (int)stp->act1_ok;      // bit 0: ACT1 holds a certified set, bit 1: ACT2 does
+        const bool from_act1 = a.warm && status == ST_INIT && a.stat_slot == 0 && a.snap_use == 0 && (okbits & 1);
         bool warm = a.warm && status == ST_INIT && (from_act1 || (((int)stp->status == 0) && ((int)stp->phase == P_DONE)));
+        // The last QP of a call (tightened bounds).  Its natural starting set is the first QP's (same A, B, q, factorisation at hand), and up to
+        // ~28 active bounds that is the cheapest start.  Beyond, the tightening moves so many touch points that the rounds cost more than an
+        // interior point -- but the set the LAST QP of the previous MPC step ended on, moved one stage with the horizon, is nearly right: on the
+        // closed loop from the script's x0 (34-39 active bounds) 4.2 rounds and no failure in 88 QPs, against 11.1 rounds and 8 failures from
+        // the first QP's set (scripts/proto/as_warm_sources.py on QPs dumped from the GPU loop).
+        const bool have_act2 = a.warm && status == ST_INIT && a.stat_slot == 1 && a.as_warm_last > 0 && (okbits & 2);
+        bool from_act2 = have_act2 && (a.as_warm_last >= 2 || !warm);
         bool big_set = false;
-        if (warm && !from_act1 && a.snap_use != 0 && a.as_warm_max_set > 0) {
+        if (warm && !from_act1 && !from_act2 && a.snap_use != 0 && a.as_warm_max_set > 0) {
             double cnt = 0.0;
             for (int e = lane; e < n; e += 64) cnt += (ACT[e] != 0.0) ? 1.0 : 0.0;
             big_set = wla::wave_sum(cnt) > (double)a.as_warm_max_set;
-            if (big_set) warm = false;
+            if (big_set) { if (have_act2) { from_act2 = true; big_set = false; } else warm = false; }
         }
+        if (from_act2) warm = true;
         const double *prev = a.primal + (size_t)b * n;
         // a later QP of the same call whose previous solve was certified: same A, B, weights, and the scratch still holds the factorisation of
         // exactly the set it starts from -- its first tick needs no factorisation at all
-        const bool keep_fact = warm && !from_act1 && a.snap_use != 0 && stp->fact_call == a.call_id && a.call_id != 0.0;
+        const bool keep_fact = warm && !from_act1 && !from_act2 && a.snap_use != 0 && stp->fact_call == a.call_id && a.call_id != 0.0;
         double set_changed = 0.0;
         double qscale = 0.0, mtot = 0.0;
 #pragma unroll 4
@@ -601,7 +615,8 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             mtot += (el.fu ? 1.0 : 0.0) + (el.fl ? 1.0 : 0.0);
             if (warm) {
                 const double ac_old = ACT[e];
-                double ac = from_act1 ? ((a.warm_shift && e + NZ < n) ? ACT1[e + NZ] : ACT1[e]) : ac_old;
+                const double *src = from_act1 ? ACT1 : ACT2;
+                double ac = (from_act1 || from_act2) ? ((a.warm_shift && e + NZ < n) ? src[e + NZ] : src[e]) : ac_old;
                 if ((ac > 0.0 && !el.fu) || (ac < 0.0 && !el.fl) || !el.fr) ac = 0.0;
                 if (ac != ac_old) set_changed = 1.0;
                 const double zp = (e < NX) ? a.x0val[(size_t)b * NX + e] : prev[e];
@@ -622,7 +637,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             s0.phase = (status == ST_INIT) ? (warm ? P_POL0 : P_INIT) : P_DONE; s0.it = 0; s0.status = status; s0.mu = 0; s0.smu = 0; s0.qscale = qscale;
             s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1; s0.ticks = 0; s0.fticks = 0; s0.tight = 0; s0.pad = 0;
             s0.snap_call = stp->snap_call; s0.snap_mu = stp->snap_mu; s0.snap_used = 0; s0.pad2 = 0;
-            s0.mode = (a.as_first && !big_set) ? 0.0 : 1.0; s0.cold_as = big_set ? 1.0 : 0.0; s0.nviol = 0; s0.path = warm ? 10.0 : (big_set ? 1.0 : 0.0);
+            s0.mode = (a.as_first && !big_set) ? 0.0 : 1.0; s0.cold_as = big_set ? 1.0 : 0.0; s0.nviol = 0; s0.path = warm ? (from_act2 ? 20.0 : 10.0) : (big_set ? 1.0 : 0.0);
             s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.uf_valid = 0; s0.res_only = 0; s0.tbox = 0; s0.stall_ref = 0; s0.stall_it = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
@@ -1038,12 +1053,12 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         const bool try_cold_as = a.as_first == 1 && s.cold_as == 0.0 && s.warm == 1.0;   // (as_first 2: a failed warm attempt goes straight to the interior point)
         s.pol_round = 0.0; s.pol_fail = 0.0; s.seth[0] = s.seth[1] = s.seth[2] = s.seth[3] = 0ULL; s.uf_valid = 0.0;
         if (!try_cold_as && a.snap_use && s.snap_call == a.call_id && a.call_id != 0.0) {
-            s.warm = -1.0; s.path = (s.path >= 10.0 ? 10.0 : 0.0) + 2.0;
+            s.warm = -1.0; s.path = 10.0 * floor(s.path / 10.0) + 2.0;
             restore_iterate(s.snap_mu);
             s.snap_used = 1.0;
             start_iter = true;
         } else {
-            const double w10 = s.path >= 10.0 ? 10.0 : 0.0;
+            const double w10 = 10.0 * floor(s.path / 10.0);
             if (try_cold_as) { s.mode = 0.0; s.path = w10 + 3.0; s.warm = -1.0; }
             else { s.mode = 1.0; s.path = w10 + 1.0; s.warm = -1.0; }
     #pragma unroll 4
@@ -1147,7 +1162,11 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             for (int o = lane; o < N * NX; o += 64) du[(o / NX) * SR + (o % NX)] = nus[o];
             if (polished && a.stat_slot == 0 && a.snap_use == 0) {     // the call's first QP: its set is where the next call's first QP starts
                 for (int e = lane; e < n; e += 64) ACT1[e] = ACT[e];
-                s.act1_ok = 1.0;
+                s.act1_ok = (double)((int)s.act1_ok | 1);
+            }
+            if (polished && a.stat_slot == 1) {                        // the call's last QP: where the next call's last QP may start (as_warm_last)
+                for (int e = lane; e < n; e += 64) ACT2[e] = ACT[e];
+                s.act1_ok = (double)((int)s.act1_ok | 2);
             }
         }
         if (polished) s.fact_call = a.call_id;
@@ -1156,7 +1175,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         if (lane == 0) {
             if (a.qpstat) {
                 int *qs = a.qpstat + ((size_t)b * 2 + a.stat_slot) * 8;
-                qs[0] = it; qs[1] = (int)stp->ticks; qs[2] = (int)stp->fticks; qs[3] = (int)nact; qs[4] = (int)s.path / 10;
+                qs[0] = it; qs[1] = (int)stp->ticks; qs[2] = (int)stp->fticks; qs[3] = (int)nact; qs[4] = (int)s.path / 10;   /* 0 cold, 1 warm (first QP: the previous call's first set; last QP: this call's first set), 2 last QP from the previous call's last set */
                 qs[5] = (int)s.pol_round; qs[6] = status; qs[7] = (int)s.path % 10;   // 0: first attempt succeeded (warm set, or empty set on a cold solve); 1: cold interior point; 2: interior point restarted from an iterate copy; 3: active set from the empty set after a failed warm attempt
             }
             if (ok) a.cost[b] = csum;

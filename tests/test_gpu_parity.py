@@ -654,7 +654,7 @@ def _script_regime_run(m, N, seeds, steps, check_kkt):
     f = cl.f
     n, mb = f.n, f.mb
     d = O.dims_of(m.nx, m.nu, m.nw, N, m.ni, m.ni_f)
-    rec = dict(success=[], qp_stats=[], x=[], u0=[], nominal_x=[], kkt_worst=0.0, kkt_checked=0)
+    rec = dict(success=[], qp_stats=[], x=[], u0=[], nominal_x=[], kkt_worst=np.zeros(4), kkt_checked=0)
     for i in range(steps):
         cl.step(W[i], fetch=False)
         qs = f.get("qp_stats", (2, 8), np.int32)
@@ -668,8 +668,8 @@ def _script_regime_run(m, N, seeds, steps, check_kkt):
                 l = np.concatenate([np.maximum(lb[b], -1e20), -x0a[b] - 1e-10]); u = np.concatenate([ub[b], -x0a[b] + 1e-10])
                 k = O.qp_kkt(d, A[b], Bm[b], m.G, m.Gf, m.Q, m.R, m.Qf, q[b], l, u, pv[b], np.concatenate([dv[b], pin[b]]))
                 scale = max(1.0, np.abs(q[b]).max())
-                worst = max(k["stationarity"] / scale, k["primal"], k["dual_sign"], k["complementarity"] / scale)
-                rec["kkt_worst"] = max(rec["kkt_worst"], worst); rec["kkt_checked"] += 1
+                rec["kkt_worst"] = np.maximum(rec["kkt_worst"], [k["stationarity"] / scale, k["primal"], k["dual_sign"] / scale, k["complementarity"] / scale])
+                rec["kkt_checked"] += 1
     cl.close()
     return {k: (np.stack(v) if isinstance(v, list) else v) for k, v in rec.items()}
 
@@ -695,7 +695,10 @@ def test_script_regime_64_seeds_30_steps_every_qp_certified_or_flagged():
     assert unsolved.sum() <= max(4, 0.005 * ran.sum()), (int(unsolved.sum()), int(ran.sum()))
     assert (st[ran] != 4).mean() > 0.99                             # solved means certified, not merely interior-point accurate
     assert ran[:, :, 0].mean() > 0.85 and r1["success"].mean() > 0.7, (ran[:, :, 0].mean(), r1["success"].mean())
-    assert r1["kkt_checked"] > 0.6 * S * steps and r1["kkt_worst"] < 1e-7, (r1["kkt_checked"], r1["kkt_worst"])
+    # independent certificate of every tightened QP reported certified: stationarity and multiplier signs 1e-8 |q|inf, complementarity 1e-7 |q|inf, primal
+    # residual (dynamics rows and boxes, absolute) 1e-6 -- the tolerance the in-kernel certificate allows the dynamics rows
+    assert r1["kkt_checked"] > 0.6 * S * steps, r1["kkt_checked"]
+    assert (r1["kkt_worst"] < np.array([1e-8, 1e-6, 1e-8, 1e-7])).all(), r1["kkt_worst"]
     assert np.isfinite(r1["x"]).all() and len({r1["x"][-1, s].tobytes() for s in range(S)}) == S      # seeds differ
 
 

@@ -232,6 +232,9 @@ def qp_statistics(stats):
         out[name] = {
             **head,
             "solved_frac": float(solved.mean()), "certified_frac": float((st == 0).mean()),
+            # status 5: primal infeasible by the interior point's Farkas certificate (the reference's OSQP reports these as primal infeasible too);
+            # 1 / 3: ended without an answer (iteration cap, stagnation, numerical)
+            "infeasible_certified_frac": float((st == 5).mean()), "unsolved_frac": float(((st == 1) | (st == 3)).mean()),
             "started_warm_frac": float((warm > 0).mean()), "started_from_previous_last_qp_set_frac": float((warm == 2).mean()), "interior_point_frac": float(cold.mean()),
             # how the solve got to its answer: first active-set attempt (warm set, or the empty set on a cold solve) / interior point from scratch /
             # interior point restarted from the first QP's iterate / active set from the empty set after a failed warm attempt

@@ -48,8 +48,10 @@ enum {
     SLSQP_ST_SOLVED = 0,      /* KKT certificate met (polished active-set solution) */
     SLSQP_ST_SOLVED_IPM = 4,  /* interior-point tolerance met, polish rejected (solution accurate to opts.eps) */
     SLSQP_ST_MAX_ITER = 1,
-    SLSQP_ST_INFEASIBLE = 2,  /* primal infeasible (x0 pin outside its box, or divergence) */
-    SLSQP_ST_NUMERICAL = 3
+    SLSQP_ST_INFEASIBLE = 2,  /* primal infeasible, seen before any work: the pinned x0 lies outside its own stage-0 box */
+    SLSQP_ST_NUMERICAL = 3,
+    SLSQP_ST_INFEASIBLE_CERT = 5 /* primal infeasible, certified by the interior point's multipliers (Farkas ray; the test OSQP applies for the
+                                    reference, eps_prim_inf = 1e-4): E'nu + lambda_u - lambda_l ~ 0 with a negative support value */
 };
 
 typedef struct {

@@ -513,7 +513,7 @@ static void harvest_kernel_events(slsqp_handle *h) {
 __global__ void k_mark_retry(int B, const int *run, const int *status, int *retry, int *count) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int r = (!run || run[b]) && status[b] != 0 && status[b] != 2;
+    const int r = (!run || run[b]) && status[b] != 0 && status[b] != 2 && status[b] != 5;      // (2, 5: infeasible for either arithmetic)
     retry[b] = r;
     if (r) atomicAdd(count, 1);
 }
@@ -524,6 +524,7 @@ static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int w
     a.qpstat = h->qpstat; a.stat_slot = stat_slot; a.diag = h->qp_diag;
     static const double snap_mu = getenv("SLSQP_SNAP_MU") ? atof(getenv("SLSQP_SNAP_MU")) : 1e-3;
     a.snap_take = snap_take; a.snap_use = snap_use && o->ipm_restart; a.snap_mu = snap_mu; a.call_id = h->call_id; a.as_first = o->as_first; a.as_rounds = o->as_rounds; a.as_max_viol = o->as_max_viol; a.as_warm_max_set = o->as_warm_max_set; a.as_warm_last = o->as_warm_last;
+    { static const double pe = getenv("SLSQP_PINF_EPS") ? atof(getenv("SLSQP_PINF_EPS")) : 1e-4; a.pinf_eps = pe; }
     { static const int ws = getenv("SLSQP_WARM_SHIFT") ? atoi(getenv("SLSQP_WARM_SHIFT")) : 1; a.warm_shift = ws ? warm_shift : 0; }
     a.prox = prox; a.prox_stride = 12; a.inst_launches = h->inst_launches;
     a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;

@@ -18,9 +18,11 @@ for i in range(steps):
     for slot in (0, 1):
         st, tk, its = qs[:, slot, 6], qs[:, slot, 1], qs[:, slot, 0]
         ran = (st != -1) & (st != 2)
-        big = ran & (tk > 40)
-        line += (f" | QP{slot+1} ran {ran.mean():.2f} status(0,1,3,4) {[(st[ran] == v).sum() for v in (0, 1, 3, 4)]} ticks mean {tk[ran].mean() if ran.any() else 0:.1f} max {tk.max()}"
-                 f" >40 ticks: {big.sum()} (status {np.bincount(st[big], minlength=5).tolist() if big.any() else []}, its max {its[big].max() if big.any() else 0})")
+        big = ran & (tk > 30)
+        rd = qs[:, slot, 5]
+        first = ran & (qs[:, slot, 7] == 0)
+        line += (f" | QP{slot+1} ran {ran.mean():.2f} status(0,1,3,4,5) {[(st[ran] == v).sum() for v in (0, 1, 3, 4)]} ticks mean {tk[ran].mean() if ran.any() else 0:.1f} max {tk.max()}"
+                 f" rounds(first-attempt ok) p50/p90/p99/max {np.percentile(rd[first], [50, 90, 99, 100]).astype(int).tolist() if first.any() else []} fallbacks {int((ran & (qs[:, slot, 7] != 0)).sum())} >30 ticks: {big.sum()} (status {np.bincount(st[big], minlength=6).tolist() if big.any() else []}, its max {its[big].max() if big.any() else 0})")
     t = cl.f.timing_ms()
     print(line + f" | gpu ms: total {t['total']:.2f} qp {t['qp']:.2f} sweep {t['sweep']:.2f} jac {t['jac']:.2f}", flush=True)
 cl.close()

@@ -139,7 +139,7 @@ def ipm_backend(qp, l, u):
     """Exact solve of the oracle QP object's problem by the dense Mehrotra interior point of tests/ref_ipm.py (nothing in common with the ADMM
     restatement or the GPU solver), returned in the reference's row layout (qp_jit.py:101-123: per stage nx dynamics rows + ni rows of G = [I;-I],
     then the terminal rows, then the x0 pin) with OSQP's sign convention for y.  Box constraints G = [I;-I] only."""
-    from ref_ipm import build_equalities, qp_box
+    from ref_ipm import build_equalities, polish, qp_box
     d = qp.d
     nx, nu, N, ni = d.nx, d.nu, d.N, d.ni
     nz, SR = nx + nu, nx + d.ni
@@ -159,6 +159,10 @@ def ipm_backend(qp, l, u):
     if viol > 1e-9:
         return np.zeros(n), np.zeros(len(l)), _Info(False, 0, 0.0)
     z, nu_, lu, ll, ok, its = qp_box(Pd, qp.q, E, e, lo, hi)
+    if ok:      # exact multipliers from the identified active set (the reference's OSQP polishes too); kept only when certified
+        zp, nup, lup, llp, polished = polish(Pd, qp.q, E, e, lo, hi, z, lu, ll)
+        if polished:
+            z, nu_, lu, ll = zp, nup, lup, llp
     y = np.zeros(len(l))
     for k in range(N):
         y[k * SR:k * SR + nx] = nu_[nx * (k + 1):nx * (k + 2)]

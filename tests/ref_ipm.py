@@ -72,3 +72,35 @@ def qp_box(Pd, q, E, e, lo, hi, tol=1e-12, max_it=100):
         a = min(1.0, 0.99 * min(steplen(dsu, su, fu), steplen(dsl, sl, fl), steplen(dlu, lu, fu), steplen(dll, ll, fl)))
         z, nu, su, sl, lu, ll = z + a * dz, nu + a * dnu, su + a * dsu, sl + a * dsl, lu + a * dlu, ll + a * dll
     return z, nu, lu, ll, False, max_it
+
+
+def polish(Pd, q, E, e, lo, hi, z, lu, ll, tol=1e-9):
+    """Active-set refinement of an interior-point answer (what OSQP's polish does for the reference, qp_jit.py:546): the bounds the iterate
+    identifies as active are fixed, the remaining equality-constrained QP is solved exactly (dense KKT system + one refinement step), and the
+    result replaces the iterate if it is feasible with multipliers of the right sign -- primal and multipliers then carry rounding error only
+    (the interior point's own multipliers are good to ~1e-6 |q|inf near a degenerate bound).  Returns (z, nu, lu, ll, polished)."""
+    n = len(q)
+    fu, fl = hi < 1e19, lo > -1e19
+    aU = fu & (lu > hi - z)
+    aL = fl & ~aU & (ll > z - lo)
+    fixed = aU | aL
+    fr = ~fixed
+    zf = np.where(aU, hi, np.where(aL, lo, 0.0))
+    Ef = E[:, fr]
+    ne = E.shape[0]
+    K = np.block([[np.diag(Pd[fr]), Ef.T], [Ef, np.zeros((ne, ne))]])
+    rhs = np.concatenate([-q[fr], e - E[:, fixed] @ zf[fixed]])
+    try:
+        lup = sla.lu_factor(K)
+        sol = sla.lu_solve(lup, rhs)
+        sol += sla.lu_solve(lup, rhs - K @ sol)
+    except Exception:
+        return z, None, lu, ll, False
+    zp = zf.copy(); zp[fr] = sol[:fr.sum()]
+    nup = sol[fr.sum():]
+    gr = Pd * zp + q + E.T @ nup                   # = -(lu - ll) on fixed elements, 0 on free ones
+    lup_, llp = np.where(aU, -gr, 0.0), np.where(aL, gr, 0.0)
+    scale = max(1.0, np.abs(q).max())
+    ok = (np.isfinite(sol).all() and lup_.min() > -tol * scale and llp.min() > -tol * scale
+          and (zp - hi)[fu].max(initial=-1.0) < tol and (lo - zp)[fl].max(initial=-1.0) < tol and np.abs(gr[fr]).max(initial=0.0) < tol * scale)
+    return (zp, nup, lup_, llp, True) if ok else (z, None, lu, ll, False)

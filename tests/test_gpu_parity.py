@@ -687,12 +687,14 @@ def test_script_regime_64_seeds_30_steps_every_qp_certified_or_flagged():
     for k in ("x", "u0", "nominal_x", "success", "qp_stats"):
         assert np.array_equal(r1[k], r2[k]), k
     st = r1["qp_stats"][..., 6]                                    # (steps, S, 2)
-    assert np.isin(st, (-1, 0, 1, 2, 3, 4)).all()
+    assert np.isin(st, (-1, 0, 1, 2, 3, 4, 5)).all()
     ran = (st != -1) & (st != 2)
     unsolved = ran & ~np.isin(st, (0, 4))
-    # bench.py's 30-step line of this regime (profiles/r03): <= 0.3 % of the QPs that ran end unsolved (infeasible tightened QPs whose x0 is inside
-    # its box); 64 x 30 x 2 = 3840 QPs here, so allow a handful
+    # bench.py's 30-step line of this regime (profiles/r03): <= 0.3 % of the QPs that ran end without a solution -- nearly all of them tightened QPs
+    # that are infeasible although their x0 is inside its box, ended by the interior point's Farkas certificate (status 5) after ~10 iterations;
+    # 64 x 30 x 2 = 3840 QPs here, so allow a handful
     assert unsolved.sum() <= max(4, 0.005 * ran.sum()), (int(unsolved.sum()), int(ran.sum()))
+    assert (ran & np.isin(st, (1, 3))).sum() <= 2, np.argwhere(ran & np.isin(st, (1, 3)))
     assert (st[ran] != 4).mean() > 0.99                             # solved means certified, not merely interior-point accurate
     assert ran[:, :, 0].mean() > 0.85 and r1["success"].mean() > 0.7, (ran[:, :, 0].mean(), r1["success"].mean())
     # independent certificate of every tightened QP reported certified: stationarity and multiplier signs 1e-8 |q|inf, complementarity 1e-7 |q|inf, primal

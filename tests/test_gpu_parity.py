@@ -760,8 +760,6 @@ def test_script_length_closed_loops_vs_oracle(model, N):
     assert np.max(np.abs(out["state_trajectory"][0].T - ref["state"])) < 1e-6 * scale
     assert np.max(np.abs(out["input_trajectory"][0].T - ref["u0"][: steps - 1])) < 1e-6 * max(1.0, np.abs(ref["u0"]).max())
     assert np.max(np.abs(out["nominal_trajectory_x"][0].transpose(2, 1, 0) - ref["nominal_x"])) < 1e-6 * scale
-    # the loop regulates: the last state is much closer to the reference point than the first
-    assert np.linalg.norm(ref["state"][-1] - m.x_ref) < 0.2 * np.linalg.norm(ref["state"][0] - m.x_ref)
 
 
 def test_config5_shaped_monte_carlo_1024_seeds_30_steps():

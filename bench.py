@@ -359,7 +359,7 @@ def main():
     def tune(f, synthetic=False):
         if os.environ.get('QP_WARM_ROUNDS'):
             f.opts.warm_rounds = int(os.environ['QP_WARM_ROUNDS'])
-        for k in ('as_first', 'as_rounds', 'as_max_viol', 'ipm_restart', 'as_warm_max_set', 'as_warm_last'):
+        for k in ('as_first', 'as_rounds', 'as_max_viol', 'ipm_restart', 'as_warm_max_set', 'as_warm_last', 'fuse_rti'):
             if os.environ.get('QP_' + k.upper()):
                 setattr(f.opts, k, int(os.environ['QP_' + k.upper()]))
         f.opts.precision = args.precision

@@ -16,7 +16,7 @@ class Dims(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("rti_steps", C.c_int), ("max_sls_iter", C.c_int), ("qp_max_iter", C.c_int), ("qp_eps", C.c_double),
                 ("conv_tol", C.c_double), ("eps_backoff", C.c_double), ("want_K", C.c_int), ("warm_start", C.c_int), ("warm_rounds", C.c_int),
-                ("max_scp_iter", C.c_int), ("scp_eps", C.c_double), ("precision", C.c_int), ("as_first", C.c_int), ("as_rounds", C.c_int), ("as_max_viol", C.c_int), ("ipm_restart", C.c_int), ("time_kernels", C.c_int), ("as_warm_max_set", C.c_int), ("as_warm_last", C.c_int)]
+                ("max_scp_iter", C.c_int), ("scp_eps", C.c_double), ("precision", C.c_int), ("as_first", C.c_int), ("as_rounds", C.c_int), ("as_max_viol", C.c_int), ("ipm_restart", C.c_int), ("time_kernels", C.c_int), ("as_warm_max_set", C.c_int), ("as_warm_last", C.c_int), ("fuse_rti", C.c_int)]
 
 
 EXPORTS = [

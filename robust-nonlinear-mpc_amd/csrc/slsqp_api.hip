@@ -32,7 +32,7 @@ extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
     o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-6; o->conv_tol = 1e-3;
     o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 20;
-    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0; o->as_first = 2; o->as_rounds = 24; o->as_max_viol = 64; o->ipm_restart = 1; o->as_warm_max_set = 28; o->as_warm_last = 1;
+    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0; o->as_first = 2; o->as_rounds = 24; o->as_max_viol = 64; o->ipm_restart = 1; o->as_warm_max_set = 28; o->as_warm_last = 1; o->fuse_rti = 1;
 }
 
 struct slsqp_handle {
@@ -50,8 +50,9 @@ struct slsqp_handle {
     int *status, *iters, *itnum, *has_prev, *conv, *alive, *mask, *success, *infeas, *counter;
     int *scp_active, *scp_success, *scp_iters, *pending_reset, *scp_upd; double *scp_dmax;
     int horizon_shifted = 0;
-    // timeline: event pairs recorded on the stream with a role (0 QP, 1 sweep, 2 whole solve, 3 linearisation); read after a synchronisation
-    std::vector<hipEvent_t> tl; std::vector<int> tl_role; int tl_n = 0; double tl_acc[4] = {0, 0, 0, 0};
+    // timeline: event pairs recorded on the stream with a role (0 QP, 1 sweep, 2 whole solve, 3 linearisation, 4 fused RTI chain); read after a synchronisation
+    std::vector<hipEvent_t> tl; std::vector<int> tl_role; int tl_n = 0; double tl_acc[5] = {0, 0, 0, 0, 0};     // role 4: fused RTI chain launches (k_rti_chain)
+    unsigned long long *chain_times = nullptr, *chain_times_host = nullptr;   // (B,4) in-kernel wall-clock ticks per instance; pinned copy of instance 0's
     int *qp_diag = nullptr;     // QP_DIAG_SPAN builds only
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
     int *retry; int mx_retry, mx_retry_total;
@@ -160,10 +161,12 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(h->owned, &h->retry, B); h->mx_retry = 0; h->mx_retry_total = 0;
     rc |= dalloc(h->owned, &h->nom_st, B * 12); rc |= dalloc(h->owned, &h->nom_need_lin, B); rc |= dalloc(h->owned, &h->nom_status, B); rc |= dalloc(h->owned, &h->nom_iters, B);
     rc |= dalloc(h->owned, &h->mapA, (size_t)N * nx * nx); rc |= dalloc(h->owned, &h->mapB, (size_t)N * nx * nu);
-    rc |= dalloc(h->owned, &h->inst_launches, (size_t)8); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
+    rc |= dalloc(h->owned, &h->inst_launches, (size_t)8); rc |= dalloc(h->owned, &h->chain_times, B * 4); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
     rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->Kc, B * N * nu * nx); rc |= dalloc(h->owned, &h->Aclc, B * N * nx * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->Gd, (size_t)ni * (nx + nu)); rc |= dalloc(h->owned, &h->Gfd, (size_t)nif * nx); h->general_G = false; h->beta_inited = false; rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
     h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { free_all(h->owned); hipStreamDestroy(h->st); delete h; return nullptr; }
+    if (hipHostMalloc((void **)&h->chain_times_host, 4 * sizeof(unsigned long long)) != hipSuccess) h->chain_times_host = nullptr;
+    else memset(h->chain_times_host, 0, 4 * sizeof(unsigned long long));
     for (auto &e : h->ev) hipEventCreate(&e);
     h->tl.resize(2 * 256); for (auto &e : h->tl) hipEventCreate(&e);
     h->tl_role.assign(256, 0); h->tl_n = 0;
@@ -208,7 +211,7 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     reg("nominal_x", h->Xn, sizeof(double) * (N + 1) * nx); reg("nominal_u", h->Un, sizeof(double) * N * nu); reg("x_meas", h->xmeas, sizeof(double) * nx); reg("u0", h->u0, sizeof(double) * nu);
     reg("A", h->A, sizeof(double) * N * nx * nx); reg("Bm", h->Bm, sizeof(double) * N * nx * nu); reg("c", h->c, sizeof(double) * N * nx);
     reg("g", h->g, sizeof(double) * N * ni); reg("gN", h->gN, sizeof(double) * nif); reg("q", h->q, sizeof(double) * h->n); reg("pin_dual", h->pin_dual, sizeof(double) * nx);
-    reg("primal_infeasibility", h->pinf, sizeof(double)); reg("qp_stats", h->qpstat, sizeof(int) * 16); reg("x0_arg", h->x0arg, sizeof(double) * nx);
+    reg("chain_times", h->chain_times, sizeof(unsigned long long) * 4); reg("primal_infeasibility", h->pinf, sizeof(double)); reg("qp_stats", h->qpstat, sizeof(int) * 16); reg("x0_arg", h->x0arg, sizeof(double) * nx);
 #ifdef QP_DIAG_SPAN
     if (dalloc(h->owned, &h->qp_diag, B * 64)) return nullptr;
     reg("qp_diag", h->qp_diag, sizeof(int) * 64);
@@ -223,6 +226,7 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     free_all(h->log_owned);
     free_all(h->owned);
     if (h->stage) hipFree(h->stage);
+    if (h->chain_times_host) hipHostFree(h->chain_times_host);
     for (auto &e : h->ev) hipEventDestroy(e);
     for (auto &e : h->tl) hipEventDestroy(e);
     for (auto &e : h->kev) hipEventDestroy(e);
@@ -451,6 +455,115 @@ __global__ __launch_bounds__(256) void k_solve_begin(SolveBeginArgs a) {
     for (int o = tid; o < N * i.NU; o += blockDim.x) i.backoff_u[(size_t)b * N * i.NU + o] = 0.0;
 }
 
+// k_after_qp for ONE wave (the fused chain kernel below): the same steps in the same order, reductions through the wave instead of LDS.
+__device__ __forceinline__ int after_qp_wave(const AfterQpArgs &a, int b, int lane) {
+    int alive = a.alive[b];
+    if (alive) { const int st = a.status[b]; if (!(st == 0 || st == 4)) { alive = 0; if (lane == 0) { a.alive[b] = 0; a.infeas[b] = 1; } } }
+    const EtaArgs &e = a.ea;
+    if (alive) {       // ---- evaluate_dual_eta
+        const int SR = e.NX + e.NI, mb = e.N * SR + e.NIF;
+        const double *du = e.dual + (size_t)b * mb;
+        double *et = e.eta + (size_t)b * e.N * e.N * e.NI, *ef = e.eta_f + (size_t)b * (e.N + 1) * e.NIF;
+        if (e.first_iter) {
+            const double s0 = 2.0 * sqrt(e.eps);
+            for (int o = lane; o < e.N * e.NI; o += 64) { const int i = o % e.NI, k = o / e.NI; et[((size_t)k * e.N) * e.NI + i] = du[k * SR + e.NX + i] / s0; }
+            for (int o = lane; o < e.NIF; o += 64) ef[o] = du[e.N * SR + o] / s0;
+        } else {
+            const double *be = e.beta + (size_t)b * e.N * e.N * e.NI, *bf = e.beta_f + (size_t)b * (e.N + 1) * e.NIF;
+            for (int o = lane; o < e.N * e.N * e.NI; o += 64) {
+                const int i = o % e.NI, j = (o / e.NI) % e.N, k = o / (e.NI * e.N);
+                if (j <= k) et[o] = du[k * SR + e.NX + i] / (2.0 * sqrt(fmax(be[o], e.eps)));
+            }
+            for (int o = lane; o < (e.N + 1) * e.NIF; o += 64) ef[o] = du[e.N * SR + (o % e.NIF)] / (2.0 * sqrt(fmax(bf[o], e.eps)));
+        }
+    }
+    int cv = 0;
+    const ConvArgs &c = a.ca;
+    if (alive) {       // ---- check_convergence_socp
+        const double *p = c.primal + (size_t)b * c.n;
+        double *q = c.prev + (size_t)b * c.n;
+        double d = 0.0;
+        for (int o = lane; o < c.n; o += 64) { d = fmax(d, fabs(p[o] - q[o])); q[o] = p[o]; }
+        d = wla::wave_max(d);
+        cv = (c.has_prev[b] && d <= c.tol) ? 1 : 0;
+    }
+    int st = a.stale[b];
+    if (alive) st = e.first_iter ? ((st & ~1) | 16) : (st & ~(1 | 16));
+    int m = 0;                                                                        // ---- mask
+    if (alive && !cv) m = 1;
+    if (m) st = (st & ~(2 | 32)) | 8;
+    const bool repair = a.first_iter && !((a.active && !a.active[b]) || m || !(st & 8));
+    wla::wsync_mem();                  // every lane has read has_prev / stale / alive before lane 0 rewrites them
+    if (lane == 0) {
+        if (alive) c.has_prev[b] = 1;
+        a.conv[b] = cv;
+        if (alive && cv) { a.success[b] = 1; if (!a.rti) a.alive[b] = 0; }
+        a.mask[b] = m;
+        if (m) { a.itnum[b] += 1; if (!a.rti) atomicAdd(a.counter, 1); }
+        a.stale[b] = repair ? (st & ~8) : st;
+    }
+    if (repair) {      // ---- beta repair
+        double *be = a.beta_w + (size_t)b * e.N * e.N * e.NI, *bf = a.beta_f_w + (size_t)b * (e.N + 1) * e.NIF;
+        for (int o = lane; o < e.N * e.N * e.NI; o += 64) be[o] = e.eps;
+        for (int o = lane; o < (e.N + 1) * e.NIF; o += 64) bf[o] = e.eps;
+    }
+    return m;
+}
+
+// One RTI fast-SLS solve (fast_SLS.solve with rti_steps = 1, the rocket script's setting: QP -> eta -> Riccati / propagation / back-offs ->
+// tightened bounds -> QP) of one instance by ONE wave in ONE launch.  The separate launches (k_qp_solve, k_after_qp, k_sweep_ric1, k_sweep_prop,
+// k_tighten, k_qp_solve) put a batch-wide barrier behind each QP: every launch lasts as long as its slowest instance (a failed warm attempt
+// followed by the interior point: 50-90 block solves against a mean of 10), so the step pays max(QP #1) + max(QP #2).  Here an instance that is
+// slow in one QP only delays itself and the step pays max over the instances of their own sums.  Same device functions, same arithmetic, same bits.
+struct ChainArgs {
+    QpArgs q1, q2;
+    AfterQpArgs aq;
+    SweepSharedArgs sw;
+    TightenArgs ta;
+    const int *active; int *success; const int *infeas;      // k_finish
+    unsigned long long *times;      // (B,4) or NULL: wall_clock64 ticks (100 MHz) of QP #1, the sweep part, QP #2 of each instance
+    int max_ticks;
+};
+template <int NX, int NU>
+__global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_rti_chain(ChainArgs c) {
+    int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= c.q1.B) return;
+    extern __shared__ double sm[];
+    unsigned long long t0 = wall_clock64(), t1 = t0, t2 = t0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        asm volatile("" : "+s"(b));
+        asm volatile("" : "+v"(lane));
+        qp_solve_dev<NX, NU, false>(pass == 0 ? c.q1 : c.q2, b, lane, sm, c.max_ticks);
+        wla::wsync_mem();
+        if (pass == 1) break;
+        t1 = wall_clock64();
+        asm volatile("" : "+s"(b));
+        asm volatile("" : "+v"(lane));
+        const int m = __builtin_amdgcn_readfirstlane(after_qp_wave(c.aq, b, lane));      // (wave-uniform by construction; said so to the compiler)
+        wla::wsync_mem();
+        if (m) {       // Riccati + tightening for this instance (fast_SLS_jit.py:321-322)
+            sweep_ric1_dev<NX, NU>(c.sw, b, lane, sm);
+            wla::wsync_mem();
+#pragma unroll 1
+            for (int j = 0; j <= c.sw.s.N; j++) {
+                asm volatile("" : "+v"(lane));
+                sweep_prop_dev<NX, NU>(c.sw, b, j, lane, sm);
+                wla::wsync();
+            }
+            wla::wsync_mem();
+            tighten_dev(c.ta, b, lane, 64);
+            wla::wsync_mem();
+        }
+        t2 = wall_clock64();
+    }
+    if (lane == 0) {
+        if (c.active && !c.active[b]) c.success[b] = 0;
+        else c.success[b] = (!c.infeas[b]) || c.success[b];           // fast_SLS_jit.py:295 (k_finish, RTI)
+        if (c.times) { const unsigned long long t3 = wall_clock64(); unsigned long long *t = c.times + (size_t)b * 4; t[0] = t1 - t0; t[1] = t2 - t1; t[2] = t3 - t2; t[3] = t3 - t0; }
+    }
+}
+
 __global__ void k_reset_stale(int *p, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = (p[i] & 8) | 3; }   // eta, K: zero on demand; beta keeps its state
 // instances whose `bit` is set in stale[]: zero their slice of arr1 (and arr2), then clear the bit (last use decides: clear_bit)
 __global__ void k_zero_stale(int *stale, int bit, double *arr1, size_t n1, double *arr2, size_t n2) {
@@ -485,14 +598,15 @@ __global__ void k_join_y(int B, int mb, int nx, const double *dual, const double
 }
 
 // ---- kernel dispatch ---------------------------------------------------------------------------------------
+// ticks a QP solve may take: 1 (start) + 2 per interior-point iteration + (1 + n_refine) per polish round, after at most warm_rounds + as_rounds
+// active-set rounds of the attempts that precede the interior point
+static int qp_max_ticks(const QpArgs &a, int max_iter) { return 1 + 2 * max_iter + 3 + 2 * 10 + 8 + 2 + 16 + 2 * (a.warm_rounds + a.as_rounds + 2); }
 template <int NX, int NU>
 static int launch_qp_t(slsqp_handle *h, const QpArgs &a, int max_iter, bool mx) {
     // the LDS of a QP wave also holds two n-vectors of the phase logic between the sweeps (phase_update, fused look)
     const size_t lds = std::max(mx ? QpLdsMx<NX, NU>::BYTES : sizeof(double) * (size_t)qp_lds_doubles<NX, NU>(h->d.N), sizeof(double) * (size_t)(2 * h->n + 8));
     const dim3 grid(h->B), blk(64);
-    // every instance needs 1 (start) + 2 per interior-point iteration + (1 + n_refine) per polish round ticks, after at most warm_rounds + as_rounds
-    // active-set rounds of the attempts that precede the interior point
-    const int max_ticks = 1 + 2 * max_iter + 3 + 2 * 10 + 8 + 2 + 16 + 2 * (a.warm_rounds + a.as_rounds + 2);
+    const int max_ticks = qp_max_ticks(a, max_iter);
     // one launch per QP solve: every wave runs its instance to completion (k_qp_solve)
     const bool timed = h->time_kernels && h->n_kev + 2 <= (int)h->kev.size();
     if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
@@ -518,8 +632,8 @@ __global__ void k_mark_retry(int B, const int *run, const int *status, int *retr
     if (r) atomicAdd(count, 1);
 }
 
-static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr, int stat_slot = 0, int snap_take = 0, int snap_use = 0,
-                     int warm_shift = 0) {
+static QpArgs make_qp_args(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr, int stat_slot = 0, int snap_take = 0, int snap_use = 0,
+                           int warm_shift = 0) {
     QpArgs a;
     a.qpstat = h->qpstat; a.stat_slot = stat_slot; a.diag = h->qp_diag;
     static const double snap_mu = getenv("SLSQP_SNAP_MU") ? atof(getenv("SLSQP_SNAP_MU")) : 1e-3;
@@ -533,10 +647,17 @@ static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int w
     a.state = h->qpstate; a.warm = warm; a.warm_rounds = o->warm_rounds;
     a.init_s = getenv("SLSQP_INIT_S") ? atof(getenv("SLSQP_INIT_S")) : 1.0; a.init_lam = getenv("SLSQP_INIT_LAM") ? atof(getenv("SLSQP_INIT_LAM")) : 0.0;
     const bool mx = o->precision == 1;
-    h->time_kernels = o->time_kernels != 0;
     a.n_refine = mx ? 3 : 1;   // fp64: one refinement solve; its forward sweep measures the dynamics residual of the first solve (certificate)
     if (getenv("SLSQP_NREFINE")) a.n_refine = atoi(getenv("SLSQP_NREFINE"));
     a.early_ctol = mx ? 1e-2 : 1e-6;
+    return a;
+}
+
+static int launch_qp(slsqp_handle *h, const int *run, const slsqp_opts *o, int warm, const double *prox = nullptr, int stat_slot = 0, int snap_take = 0, int snap_use = 0,
+                     int warm_shift = 0) {
+    const QpArgs a = make_qp_args(h, run, o, warm, prox, stat_slot, snap_take, snap_use, warm_shift);
+    const bool mx = o->precision == 1;
+    h->time_kernels = o->time_kernels != 0;
     auto go = [&](const QpArgs &q, bool m) {
 #define X(NX_, NU_) if (h->d.nx == NX_ && h->d.nu == NU_) return launch_qp_t<NX_, NU_>(h, q, o->qp_max_iter, m);
         SLSQP_DIM_LIST
@@ -604,6 +725,19 @@ static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, cons
     return -1;
 }
 
+// the fused RTI chain (k_rti_chain): one launch for QP #1 -> eta -> shared Riccati + propagation -> tightened bounds -> QP #2
+template <int NX, int NU>
+static int launch_chain_t(slsqp_handle *h, ChainArgs &c) {
+    const size_t lds = sizeof(double) * std::max({(size_t)qp_lds_doubles<NX, NU>(h->d.N), (size_t)(2 * h->n + 8), (size_t)sweep_lds_doubles<NX, NU>(), (size_t)sweep_prop_lds_doubles<NX, NU>()});
+    const bool timed = h->time_kernels && h->n_kev + 2 <= (int)h->kev.size();
+    if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
+    hipLaunchKernelGGL((k_rti_chain<NX, NU>), dim3(h->B), dim3(64), lds, h->st, c);
+    if (timed) { hipEventRecord(h->kev[h->n_kev + 1], h->st); h->n_kev += 2; }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static bool chain_allowed() { static const bool v = getenv("SLSQP_FUSE_RTI") ? atoi(getenv("SLSQP_FUSE_RTI")) != 0 : true; return v; }
+
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
 
 // `active` (device, B ints or NULL = all): instances that take part in this call; the others keep every result array untouched.
@@ -625,7 +759,14 @@ static void tl_flush(slsqp_handle *h) {
 static void tl_take(slsqp_handle *h) {     // accumulators -> the handle's timing fields (what slsqp_last_timing reports)
     tl_flush(h);
     h->t_qp = h->tl_acc[0]; h->t_sweep = h->tl_acc[1]; h->t_total = h->tl_acc[2]; h->t_jac = h->tl_acc[3];
-    h->tl_acc[0] = h->tl_acc[1] = h->tl_acc[2] = h->tl_acc[3] = 0;
+    if (h->tl_acc[4] > 0.0) {
+        // fused RTI chain launches: no batch-wide "QP time" / "sweep time" exists any more.  Reported: the sweep part as instance 0 spent it inside
+        // the kernel (wall clock, 100 MHz; what the reference's single-instance t_backward_ms measures), the rest of the launches' duration as QP time
+        double sw = 0.0;
+        if (h->chain_times_host) sw = std::min(h->tl_acc[4], (double)h->chain_times_host[1] * 1e-5);
+        h->t_sweep += sw; h->t_qp += h->tl_acc[4] - sw;
+    }
+    h->tl_acc[0] = h->tl_acc[1] = h->tl_acc[2] = h->tl_acc[3] = h->tl_acc[4] = 0;
 }
 
 // no_sync: return with the launches queued (the caller synchronises the stream later and then calls tl_take)
@@ -677,6 +818,36 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         } else hipLaunchKernelGGL(k_init_backoff, dim3(B), dim3(256), 0, h->st, ia);
         h->beta_inited = true;
     }
+    }
+    if (rti && steps == 1 && o.precision == 0 && o.fuse_rti && chain_allowed() && sweep_shared_allowed() && !h->general_G) {
+        // fast_SLS.solve with rti_steps = 1 (the rocket script's setting) as ONE launch: every wave takes its instance through the whole chain
+        h->time_kernels = o.time_kernels != 0;
+        ChainArgs c;
+        c.q1 = make_qp_args(h, h->alive, &o, o.warm_start ? 1 : 0, nullptr, 0, 1, 0, wshift);
+        c.q2 = make_qp_args(h, h->alive, &o, 1, nullptr, 1, 1, 1, wshift);
+        EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff, h->stale, 1};
+        ConvArgs ca{B, h->n, h->primal, h->prev_primal, h->has_prev, h->alive, h->conv, o.conv_tol};
+        c.aq = AfterQpArgs{B, 1, 1, h->status, active, h->alive, h->infeas, h->mask, h->success, h->itnum, h->counter, h->stale, h->conv, ea, ca, h->beta, h->beta_f};
+        SweepArgs sa;
+        sa.B = h->B; sa.N = d.N; sa.NW = d.nw; sa.A = h->A; sa.Bm = h->Bm; sa.E = h->E; sa.E_per_instance = 0; sa.eta = h->eta; sa.eta_f = h->eta_f;
+        sa.run = h->mask; sa.cst = costs_of(h); sa.K = h->K; sa.beta = h->beta; sa.beta_f = h->beta_f; sa.ct_part = h->ct_part; sa.eps = o.eps_backoff;
+        c.sw = SweepSharedArgs{sa, h->Kc, h->Aclc, h->stale};
+        c.ta = TightenArgs{B, d.N, d.nx, d.nu, d.ni, d.ni_f, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1, h->ct_part, h->cost_tube};
+        c.active = active; c.success = h->success; c.infeas = h->infeas; c.times = h->chain_times;
+        c.max_ticks = qp_max_ticks(c.q1, o.qp_max_iter);
+        const int tl_c = tl_begin(h, 4);
+        int rc = -1;
+#define X(NX_, NU_) if (d.nx == NX_ && d.nu == NU_) rc = launch_chain_t<NX_, NU_>(h, c);
+        SLSQP_DIM_LIST
+#undef X
+        if (rc) return -1;
+        tl_end(h, tl_c);
+        if (h->chain_times_host) HIPCHK(hipMemcpyAsync(h->chain_times_host, h->chain_times, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->st));
+        tl_end(h, tl_tot);
+        if (no_sync) return 0;
+        HIPCHK(hipStreamSynchronize(h->st));
+        tl_take(h);
+        return 0;
     }
     for (int i = 0; i < steps; i++) {
         const int tl_q = tl_begin(h, 0);

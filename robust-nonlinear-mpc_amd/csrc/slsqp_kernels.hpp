@@ -1228,14 +1228,11 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
 #define QP_PERSIST_WAVES_PER_SIMD 3
 #endif
 template <int NX, int NU, bool MX = false>     // MX: the mixed-precision sweeps (ne_forward_mx / ne_backward_mx, section 2.4 of DESIGN.md), same loop and phase logic
-__global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpArgs a, int max_ticks) {
-    int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B) return;
+__device__ __forceinline__ void qp_solve_dev(const QpArgs &a, int b, int lane, double *sm, int max_ticks) {
     if (a.run && !a.run[b]) {       // not part of this solve: its statistics slot says so (status -1)
         if (a.qpstat && lane < 8) a.qpstat[((size_t)b * 2 + a.stat_slot) * 8 + lane] = (lane == 6) ? -1 : 0;
         return;
     }
-    extern __shared__ double sm[];
     phase_update<NX, NU>(a, 1, b, lane);
     wla::wsync_mem();
     unsigned long long n_sweeps = 0, n_factor = 0, n_fstages = 0, n_bwd_skipped = 0;
@@ -1293,6 +1290,13 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
     if (lane == 0) { double *kk = a.kkt + (size_t)b * 8; kk[2] = (double)c_fwdf; kk[3] = (double)(double)n_fstages; kk[4] = (double)c_fwd; kk[5] = (double)c_bwd; kk[6] = (double)c_ph; kk[7] = (double)(__builtin_readcyclecounter() - c_t0); }
 #endif
     if (lane == 0) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); atomicAdd(a.inst_launches + 2, n_fstages); atomicAdd(a.inst_launches + 3, n_sweeps ? 1ULL : 0ULL); if (n_bwd_skipped) atomicAdd(a.inst_launches + 4, n_bwd_skipped); }
+}
+template <int NX, int NU, bool MX = false>
+__global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpArgs a, int max_ticks) {
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    extern __shared__ double sm[];
+    qp_solve_dev<NX, NU, MX>(a, b, threadIdx.x, sm, max_ticks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1777,14 +1781,11 @@ struct SweepSharedArgs {
     int *stale;                // bit 32 set by k_sweep_ric1: K[k,j] = Kc[k] (j <= k) not written out yet (slsqp_get broadcasts it on demand)
 };
 template <int NX, int NU>
-__global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep_ric1(SweepSharedArgs aa) {
+__device__ __forceinline__ void sweep_ric1_dev(const SweepSharedArgs &aa, int b, int lane, double *sm) {
     const SweepArgs &a = aa.s;
     using L = Lay<NX, NU>;
     constexpr int NZ = L::NZ, NI = L::NI, NIF = L::NIF;
-    const int N = a.N, lane = threadIdx.x, b = blockIdx.x, j = 0;
-    if (b >= a.B) return;
-    if (a.run && !a.run[b]) return;
-    extern __shared__ double sm[];
+    const int N = a.N, j = 0;
     double *p = sm;
     double *sA = p; p += NX * NX; double *sS = p; p += NX * NX; double *sYm = p; p += NX * NX;
     double *sAcl = sA, *sSn = sS;
@@ -1897,32 +1898,24 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep_ric1(SweepSh
         wla::wsync();
     }
 }
+template <int NX, int NU>
+__global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep_ric1(SweepSharedArgs aa) {
+    const int b = blockIdx.x;
+    if (b >= aa.s.B) return;
+    if (aa.s.run && !aa.s.run[b]) return;
+    extern __shared__ double sm[];
+    sweep_ric1_dev<NX, NU>(aa, b, threadIdx.x, sm);
+}
 
 template <int NX, int NU>
 __host__ __device__ constexpr int sweep_prop_lds_doubles() { return 3 * NX * NX + 2 * NX * NU + 8; }
 
 template <int NX, int NU>
-__global__ __launch_bounds__(64, 4) void k_sweep_prop(SweepSharedArgs aa) {
+__device__ __forceinline__ void sweep_prop_dev(const SweepSharedArgs &aa, int b, int j, int lane, double *sm) {
     const SweepArgs &a = aa.s;
     using L = Lay<NX, NU>;
     constexpr int NZ = L::NZ, NI = L::NI, NIF = L::NIF, NW = NX;
-    const int N = a.N, lane = threadIdx.x;
-    const int ncol = N + 1;
-    int b, j;
-    {
-        const int bid = blockIdx.x;
-        const int Bfull = (a.B / 8) * 8;
-        if (bid < Bfull * ncol) {
-            const int xcd = bid % 8, slot = bid / 8;
-            b = (slot / ncol) * 8 + xcd; j = slot % ncol;
-        } else {
-            const int r = bid - Bfull * ncol;
-            b = Bfull + r / ncol; j = r % ncol;
-        }
-    }
-    if (b >= a.B) return;
-    if (a.run && !a.run[b]) return;
-    extern __shared__ double sm[];
+    const int N = a.N;
     double *p = sm;
     double *sAcl = p; p += NX * NX; double *sPhi = p; p += NX * NX; double *sPhi2 = p; p += NX * NX;
     double *sK = p; p += NX * NU; double *sPu = p; p += NU * NW;
@@ -1989,6 +1982,27 @@ __global__ __launch_bounds__(64, 4) void k_sweep_prop(SweepSharedArgs aa) {
     ctube = wla::wave_sum(ctube);
     if (lane == 0 && a.ct_part) a.ct_part[(size_t)b * (N + 1) + j] = ctube;
 }
+template <int NX, int NU>
+__global__ __launch_bounds__(64, 4) void k_sweep_prop(SweepSharedArgs aa) {
+    const SweepArgs &a = aa.s;
+    const int ncol = a.N + 1;
+    int b, j;
+    {   // XCD-aware mapping: blocks i and i+8 share an XCD; all columns of an instance stay on one XCD (its K_k, A_k + B_k K_k stay in that L2)
+        const int bid = blockIdx.x;
+        const int Bfull = (a.B / 8) * 8;
+        if (bid < Bfull * ncol) {
+            const int xcd = bid % 8, slot = bid / 8;
+            b = (slot / ncol) * 8 + xcd; j = slot % ncol;
+        } else {
+            const int r = bid - Bfull * ncol;
+            b = Bfull + r / ncol; j = r % ncol;
+        }
+    }
+    if (b >= a.B) return;
+    if (a.run && !a.run[b]) return;
+    extern __shared__ double sm[];
+    sweep_prop_dev<NX, NU>(aa, b, j, threadIdx.x, sm);
+}
 
 // ------------------------------------------------------------------------------------------------
 // backoff sums + tightened bounds (fast_SLS_jit.py:173-186, 556-569) ; one workgroup per instance
@@ -2001,15 +2015,13 @@ struct TightenArgs {
     int write_ubg;
     const double *ct_part; double *cost_tube;   // (B,N+1) -> (B): cost_tube = sqrt(sum over columns)
 };
-__global__ void k_tighten(TightenArgs a) {
-    const int b = blockIdx.x;
-    if (a.run && !a.run[b]) return;
+__device__ __forceinline__ void tighten_dev(const TightenArgs &a, int b, int tid, int nthr) {
     const int NX = a.NX, NU = a.NU, NZ = NX + NU, NI = a.NI, NIF = a.NIF, N = a.N, SR = NX + NI, mb = N * SR + NIF;
     const double *be = a.beta + (size_t)b * N * N * NI, *bf = a.beta_f + (size_t)b * (N + 1) * NIF;
     double *bo = a.backoff + (size_t)b * N * NI, *bof = a.backoff_f + (size_t)b * NIF;
     double *bx = a.backoff_x + (size_t)b * (N + 1) * NX, *bu = a.backoff_u + (size_t)b * N * NU;
     double *ub = a.ubg + (size_t)b * mb;
-    for (int o = threadIdx.x; o < N * NI; o += blockDim.x) {
+    for (int o = tid; o < N * NI; o += nthr) {
         const int k = o / NI, i = o % NI;
         double acc = 0.0;
         for (int j = 0; j <= k; j++) acc += sqrt(be[((size_t)k * N + j) * NI + i]);
@@ -2018,7 +2030,7 @@ __global__ void k_tighten(TightenArgs a) {
         else if (i < NZ) bu[k * NU + (i - NX)] = acc;
         if (a.write_ubg) ub[k * SR + NX + i] = a.g[((size_t)b * N + k) * NI + i] - acc;   // no +eps (quirk q3)
     }
-    for (int o = threadIdx.x; o < NIF; o += blockDim.x) {
+    for (int o = tid; o < NIF; o += nthr) {
         double acc = 0.0;
         for (int j = 0; j <= N; j++) acc += sqrt(bf[j * NIF + o]);
         bof[o] = acc;
@@ -2026,12 +2038,17 @@ __global__ void k_tighten(TightenArgs a) {
         if (a.write_ubg) ub[N * SR + o] = a.gf_raw[o] - acc;                               // raw gf (quirk q2)
     }
     if (a.write_ubg)
-        for (int o = threadIdx.x; o < N * NX; o += blockDim.x) ub[(o / NX) * SR + (o % NX)] = -a.c[(size_t)b * N * NX + o];
-    if (threadIdx.x == 0 && a.ct_part) {
+        for (int o = tid; o < N * NX; o += nthr) ub[(o / NX) * SR + (o % NX)] = -a.c[(size_t)b * N * NX + o];
+    if (tid == 0 && a.ct_part) {
         double acc = 0.0;
         for (int j = 0; j <= N; j++) acc += a.ct_part[(size_t)b * (N + 1) + j];
         a.cost_tube[b] = sqrt(acc);
     }
+}
+__global__ void k_tighten(TightenArgs a) {
+    const int b = blockIdx.x;
+    if (a.run && !a.run[b]) return;
+    tighten_dev(a, b, threadIdx.x, blockDim.x);
 }
 
 // initialize_backoff (fast_SLS_jit.py:444-454)

@@ -23,6 +23,11 @@ for i in range(steps):
         first = ran & (qs[:, slot, 7] == 0)
         line += (f" | QP{slot+1} ran {ran.mean():.2f} status(0,1,3,4,5) {[(st[ran] == v).sum() for v in (0, 1, 3, 4)]} ticks mean {tk[ran].mean() if ran.any() else 0:.1f} max {tk.max()}"
                  f" rounds(first-attempt ok) p50/p90/p99/max {np.percentile(rd[first], [50, 90, 99, 100]).astype(int).tolist() if first.any() else []} fallbacks {int((ran & (qs[:, slot, 7] != 0)).sum())} >30 ticks: {big.sum()} (status {np.bincount(st[big], minlength=6).tolist() if big.any() else []}, its max {its[big].max() if big.any() else 0})")
+    ct = cl.f.get("chain_times", (4,), np.int64) * 1e-5      # ms inside k_rti_chain per instance: QP1, eta + sweep + tightening, QP2, total
+    tot = ct[:, 3]
+    order = np.argsort(tot)[::-1][:3]
+    line += (f" | chain ms p50/p90/p99/max {np.percentile(tot, [50, 90, 99, 100]).round(2).tolist()} slowest: " +
+             "; ".join(f"[qp1 {ct[i,0]:.2f} sw {ct[i,1]:.2f} qp2 {ct[i,2]:.2f} | ticks {qs[i,0,1]}/{qs[i,1,1]} st {qs[i,0,6]}/{qs[i,1,6]} its {qs[i,0,0]}/{qs[i,1,0]}]" for i in order))
     t = cl.f.timing_ms()
     print(line + f" | gpu ms: total {t['total']:.2f} qp {t['qp']:.2f} sweep {t['sweep']:.2f} jac {t['jac']:.2f}", flush=True)
 cl.close()

@@ -762,6 +762,39 @@ def test_script_length_closed_loops_vs_oracle(model, N):
     assert np.max(np.abs(out["nominal_trajectory_x"][0].transpose(2, 1, 0) - ref["nominal_x"])) < 1e-6 * scale
 
 
+def test_fused_rti_chain_is_bitwise_the_separate_launches():
+    """opts.fuse_rti: the one-launch RTI chain (k_rti_chain: every wave takes its instance through QP -> eta -> Riccati / propagation -> tightened
+    bounds -> QP) against the separate launches (k_qp_solve, k_after_qp, k_sweep_ric1, k_sweep_prop, k_tighten, k_qp_solve): same device functions in
+    the same order per instance, so every result array is identical bit for bit -- rocket closed loop from the script's x0 (active-set rounds,
+    interior-point fall-backs, steps flagged at x0), 96 seeds x 8 steps, and the fast-SLS result arrays of the last step."""
+    from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
+    m = get_model("rocket")
+    N, B, steps = 20, 96, 8
+    W = np.stack([disturbance_stream(s, steps, m.nx) for s in range(B)], axis=1)
+    res = []
+    for fuse in (1, 0):
+        cl = ClosedLoopMPC(m, N, B)
+        cl.f.opts.fuse_rti = fuse
+        cl.reset(np.tile(m.extra["x0"], (B, 1)), solve_nominal=True, continuation=2)
+        outs = [cl.step(W[i]) for i in range(steps)]
+        f = cl.f
+        last = {k: f.get(k, shp, dt) for k, shp, dt in (("primal_vec", (f.n,), np.float64), ("dual_vec", (f.mb,), np.float64), ("eta", (N, N, m.ni), np.float64),
+                                                         ("beta", (N, N, m.ni), np.float64), ("beta_f", (N + 1, m.ni_f), np.float64), ("K", (N, N + 1, m.nu, m.nx), np.float64),
+                                                         ("backoff", (N, m.ni), np.float64), ("ubg", (f.mb,), np.float64), ("qp_stats", (2, 8), np.int32),
+                                                         ("status", (), np.int32), ("success", (), np.int32), ("iteration_number", (), np.int32), ("cost_tube", (), np.float64))}
+        t = f.timing_ms()
+        cl.close()
+        res.append((outs, last, t))
+    (o1, l1, t1), (o0, l0, t0) = res
+    for i in range(steps):
+        for k in ("u0", "x_next", "nominal_x", "nominal_u", "backoff_x", "backoff_u", "success", "status", "primal_infeasibility"):
+            assert np.array_equal(o1[i][k], o0[i][k], equal_nan=True), (i, k)
+    for k in l1:
+        assert np.array_equal(l1[k], l0[k], equal_nan=True), k
+    assert (l1["qp_stats"][:, 1, 0] > 0).any() or (l1["qp_stats"][:, 1, 5] > 0).any()      # the loop did real work in the last step
+    assert t1["qp"] > 0 and t1["sweep"] > 0 and t0["qp"] > 0 and t0["sweep"] > 0               # both report a QP and a sweep time
+
+
 def test_config5_shaped_monte_carlo_1024_seeds_30_steps():
     """BASELINE config 5 at its per-GPU size: 1024 disturbance seeds x 30 closed-loop steps of the rocket (N = 20, script weights, rti = 1, one fast-SLS
     step) from the SCRIPT'S OWN initial state (main_rocket...:110-126; nominal by the GPU initialiser's two-stage continuation).  Properties at full size:

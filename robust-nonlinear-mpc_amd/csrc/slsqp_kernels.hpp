@@ -126,10 +126,47 @@ struct NeG {   // global-memory operands of the sweeps (this instance)
     int N;
 };
 
+// Stage blocks in flight between global memory and LDS.  A_k and B_k travel as pairs of doubles (one 16-byte load and one ds_write2_b64 per pair:
+// 3 + 1 loads per lane for the rocket instead of 5 + 2); the stored inverse D_k^-1 travels as the 2x2 blocks of its lower triangle in the lane
+// layout of the Gauss-Jordan sweep that produced it (wla::spd_inv_gj: 4 doubles per lane on 45 lanes = 1440 B instead of the full symmetric
+// 2312 B) and is mirrored to the full matrix on its way into LDS.
+template <int NX, int NU>
+struct StageIO {
+    static constexpr int MM = NX * NX, NB = NX * NU, PA = (MM + 1) / 2, PB = (NB + 1) / 2, RA = (PA + 63) / 64, RB = (PB + 63) / 64;
+    static constexpr int NT = wla::gj_blocks<NX>(), DSTR = 4 * NT;      // doubles per stored inverse
+    static_assert(NT <= 64 && DSTR <= MM, "block-packed inverse fits the scratch of the full one");
+    wla::d2 A[RA], B[RB], L[2];
+    __device__ __forceinline__ void load_AB(const double *Ak, const double *Bk, int lane) {
+#pragma unroll
+        for (int r = 0; r < RA; r++) A[r] = wla::ld2(Ak + 2 * min(r * 64 + lane, PA - 1));      // (an odd block's last pair reads one double of its successor: never stored)
+#pragma unroll
+        for (int r = 0; r < RB; r++) B[r] = wla::ld2(Bk + 2 * min(r * 64 + lane, PB - 1));
+    }
+    __device__ __forceinline__ void load_L(const double *Lk, int lane) {
+        const int l = min(lane, NT - 1);
+        L[0] = wla::ld2(Lk + 4 * l); L[1] = wla::ld2(Lk + 4 * l + 2);
+    }
+    __device__ __forceinline__ void store_AB(double *sA, double *sB, int lane) const {
+#pragma unroll
+        for (int r = 0; r < RA; r++) {
+            const int p = r * 64 + lane;
+            if (2 * p + 1 < MM) wla::st2(sA + 2 * p, A[r]);
+            else if (2 * p < MM) sA[2 * p] = A[r].x;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            const int p = r * 64 + lane;
+            if (2 * p + 1 < NB) wla::st2(sB + 2 * p, B[r]);
+            else if (2 * p < NB) sB[2 * p] = B[r].x;
+        }
+    }
+    __device__ __forceinline__ void store_L(double *sL, int lane) const { wla::gj_blocks_to_lds<NX>(L[0].x, L[0].y, L[1].x, L[1].y, sL, NX, lane); }
+};
+
 // Forward sweep over the horizon of the block-tridiagonal normal equations  Y nu = b,  Y = E Pi E':
 //   optional (re)factorisation, block LDL':  D_k = Y_kk - O_k D_{k-1}^-1 O_k',  O_k = Y_{k,k-1} = -A_k diag(pi_x,k)
-//   (explicit symmetric inverses Dinv_k kept, written to HBM scratch),
-//   rhs b_k = E_k v - eflag * e_k, forward elimination t_k = b_k - O_k u_{k-1},  u_k = Dinv_k t_k  (u_k stored in W).
+//   (explicit symmetric inverses Dinv_k kept, written block-packed to HBM scratch),
+//   rhs b_k = E_k v - eflag * e_k, forward elimination t_k = b_k - O_k u_{k-1},  u_k = Dinv_k t_k  (u_k stored in UF).
 template <int NX, int NU>
 __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool factor_all, double eflag, double delta, int lane,
                                           double *bmax_out = nullptr, int k0 = 0, int ks = 0) {
@@ -140,45 +177,32 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
     // UF) still hold and only u_{ks-1} and Dinv_{ks-1} are read back.
     double bmax = 0.0;
     using Ld = QpLds<NX, NU>;
+    using IO = StageIO<NX, NU>;
     constexpr int NZ = NX + NU, SR = NX + 2 * NZ, MM = NX * NX;
     double *sA = sm + Ld::oA, *sL1 = sm + Ld::oL1, *sB = sm + Ld::oB, *sPiS = sm + Ld::oPiS, *sVS = sm + Ld::oVS;
     double *sWp = sm + Ld::oWp, *sT1 = sm + Ld::oT1, *sT2 = sm + Ld::oT2;
     double *Lprev = sm + Ld::oP, *Lcur = sm + Ld::oQ;
     int fail = 0;
     // software pipeline: stage k+1's blocks are fetched HBM/L2 -> registers while stage k is being processed
-    constexpr int RA = (MM + 63) / 64, RB = (NX * NU + 63) / 64;
-    double rA[RA], rB[RB], rL[RA], rPi = 0.0, rV = 0.0, rE = 0.0;
+    IO io;
+    double rPi = 0.0, rV = 0.0, rE = 0.0;
     auto prefetch = [&](int k) {
-        const double *Ak = g.A + (size_t)k * MM, *Bk = g.Bm + (size_t)k * NX * NU, *Lg = g.Linv + (size_t)k * MM;
-#pragma unroll
-        for (int r = 0; r < RA; r++) rA[r] = Ak[min(r * 64 + lane, MM - 1)];
-#pragma unroll
-        for (int r = 0; r < RB; r++) rB[r] = Bk[min(r * 64 + lane, NX * NU - 1)];
-        if (!(factor_all && k >= k0)) {
-#pragma unroll
-            for (int r = 0; r < RA; r++) rL[r] = Lg[min(r * 64 + lane, MM - 1)];
-        }
+        io.load_AB(g.A + (size_t)k * MM, g.Bm + (size_t)k * NX * NU, lane);
+        if (!(factor_all && k >= k0)) io.load_L(g.Linv + (size_t)k * IO::DSTR, lane);
         const int ls = min(lane, NZ + NX - 1), lx = min(lane, NX - 1);
         rPi = g.PI[k * NZ + ls]; rV = g.V[k * NZ + ls];
         if (eflag != 0.0) rE = 0.5 * (g.ub[k * SR + lx] + g.lb[k * SR + lx]);
     };
     if (ks > 0) {
-        const double *Lg = g.Linv + (size_t)(ks - 1) * MM;
-#pragma unroll
-        for (int o = lane; o < MM; o += 64) Lprev[o] = Lg[o];
+        io.load_L(g.Linv + (size_t)(ks - 1) * IO::DSTR, lane);
+        io.store_L(Lprev, lane);
         if (lane < NX) sWp[lane] = g.UF[(ks - 1) * NX + lane];
     }
     prefetch(ks);
     for (int k = ks; k < g.N; k++) {
         const bool factor = factor_all && k >= k0;
-#pragma unroll
-        for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < MM) sA[o] = rA[r]; }
-#pragma unroll
-        for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) sB[o] = rB[r]; }
-        if (!factor) {
-#pragma unroll
-            for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < MM) Lcur[o] = rL[r]; }
-        }
+        io.store_AB(sA, sB, lane);
+        if (!factor) io.store_L(Lcur, lane);
         if (lane < NZ + NX) { sPiS[lane] = rPi; sVS[lane] = rV; }
         const double ek = rE;
         wla::wsync();
@@ -201,10 +225,8 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             if constexpr (Ld::MFMA) wla::build_Y_mfma<NX, NU>(sA, sPiS, sB, sPiS + NX, Lprev, k > 0, sPiS + NZ, delta, sY, lane);   // in place over T
             else wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
             wla::wsync();
-            fail |= wla::spd_inv_gj<NX>(sY, NX, Lcur, NX, (double *)nullptr, lane);
-            double *Lg = g.Linv + (size_t)k * MM;
-#pragma unroll
-            for (int o = lane; o < MM; o += 64) Lg[o] = Lcur[o];
+            // the inverse goes to LDS (full, for this stage's and the next stage's products) and, block-packed from the registers, to the scratch
+            fail |= wla::spd_inv_gj<NX>(sY, NX, Lcur, NX, g.Linv + (size_t)k * IO::DSTR, lane);
         }
         // rhs b = A v_x + B v_u - v_x,k+1 - eflag e_k  (+ A (pi_x,k .* Linv_{k-1}' w_{k-1}))
         // t_k = A (v_x + pi_x,k .* u_{k-1}) + B v_u - v_x,k+1 - eflag e_k   (u_{k-1} = Dinv_{k-1} t_{k-1} kept in sWp; the second term is -O_k u_{k-1})
@@ -229,6 +251,7 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
 template <int NX, int NU>
 __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int lane) {
     using Ld = QpLds<NX, NU>;
+    using IO = StageIO<NX, NU>;
     constexpr int NZ = NX + NU, MM = NX * NX;
     double *sA = sm + Ld::oA, *sLa = sm + Ld::oQ, *sB = sm + Ld::oB, *sPiS = sm + Ld::oPiS, *sWp = sm + Ld::oWp;
     double *sT1 = sm + Ld::oT1, *sT2 = sm + Ld::oT2, *sT3 = sm + Ld::oT3;
@@ -236,23 +259,17 @@ __device__ __forceinline__ void ne_backward(double *sm, const NeG<NX, NU> g, int
     wla::wsync();
     // the sweep is bound by the latency of the stage loads (A_k, B_k, Dinv_k stream through once, 2 kflop per stage): two stages are
     // kept in flight in two register sets
-    constexpr int RA = (MM + 63) / 64, RB = (NX * NU + 63) / 64;
-    struct StageRegs { double A[RA], L[RA], B[RB], Pi, W; };
+    struct StageRegs { IO io; double Pi, W; };
     StageRegs r0, r1;
     auto load = [&](int k, StageRegs &r) {
-        const double *Ak = g.A + (size_t)k * MM, *Bk = g.Bm + (size_t)k * NX * NU, *Lg = g.Linv + (size_t)k * MM;
-#pragma unroll
-        for (int q = 0; q < RA; q++) { const int o = min(q * 64 + lane, MM - 1); r.A[q] = Ak[o]; r.L[q] = Lg[o]; }
-#pragma unroll
-        for (int q = 0; q < RB; q++) r.B[q] = Bk[min(q * 64 + lane, NX * NU - 1)];
+        r.io.load_AB(g.A + (size_t)k * MM, g.Bm + (size_t)k * NX * NU, lane);
+        r.io.load_L(g.Linv + (size_t)k * IO::DSTR, lane);
         const int lx = min(lane, NX - 1);
         r.Pi = g.PI[(k + 1) * NZ + lx]; r.W = g.UF[k * NX + lx];
     };
     auto stage = [&](int k, StageRegs &r) {
-#pragma unroll
-        for (int q = 0; q < RA; q++) { const int o = q * 64 + lane; if (o < MM) { sA[o] = r.A[q]; sLa[o] = r.L[q]; } }
-#pragma unroll
-        for (int q = 0; q < RB; q++) { const int o = q * 64 + lane; if (o < NX * NU) sB[o] = r.B[q]; }
+        r.io.store_AB(sA, sB, lane);
+        r.io.store_L(sLa, lane);
         if (lane < NX) { sPiS[lane] = r.Pi; sWp[lane] = r.W; }
         wla::wsync();
         if (k >= 2) load(k - 2, r);
@@ -1227,6 +1244,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
 #ifndef QP_PERSIST_WAVES_PER_SIMD
 #define QP_PERSIST_WAVES_PER_SIMD 3
 #endif
+
 template <int NX, int NU, bool MX = false>     // MX: the mixed-precision sweeps (ne_forward_mx / ne_backward_mx, section 2.4 of DESIGN.md), same loop and phase logic
 __device__ __forceinline__ void qp_solve_dev(const QpArgs &a, int b, int lane, double *sm, int max_ticks) {
     if (a.run && !a.run[b]) {       // not part of this solve: its statistics slot says so (status -1)

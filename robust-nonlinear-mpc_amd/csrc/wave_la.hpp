@@ -52,6 +52,12 @@ __device__ __forceinline__ int wave_or(int v) {
     return v;
 }
 
+// Two consecutive doubles as one 16-byte move.  The addresses are only 8-byte aligned (stage blocks of odd size follow each other): from global
+// memory this is one global_load_dwordx4 / global_store_dwordx4 (dword alignment is all the hardware asks for), to LDS one ds_write2_b64.
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d2 ld2(const double *p) { d2 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void st2(double *p, d2 v) { __builtin_memcpy(p, &v, 16); }
+
 // C(MxN) = alpha * A(MxK) * B(NxK)' with RBxCB register blocking per lane (one pass, needs ceil(M/RB)*ceil(N/CB) <= 64).
 // Out-of-range rows/cols are clamped on load and masked on store.
 template <int M, int N, int K, int RB, int CB, typename T>
@@ -439,15 +445,35 @@ __device__ __forceinline__ double bperm_d(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+// lane (bi >= bj) of the lower-triangular 2x2 block grid -> its block of a symmetric MxM matrix, written mirrored to the full matrix in LDS
+template <int M> constexpr int gj_blocks() { return ((M + 1) / 2) * ((M + 1) / 2 + 1) / 2; }
+// row bi of lane l = bi (bi + 1) / 2 + bj, bj <= bi, in the lower-triangular block grid.  Deliberately a loop: a closed form makes the block
+// indices loop-invariant for the compiler, which then hoists every address derived from them out of the stage loop of the sweeps and keeps them in
+// registers across the factorisation (k_qp_solve: 57 -> 194 spilled VGPRs, the kernel twice as slow -- measured).
+__device__ __forceinline__ int tri_row(int l) {
+    int bi = 0, rem = l;
+    while (rem > bi) { rem -= bi + 1; bi++; }
+    return bi;
+}
 template <int M, typename R>
-__device__ __forceinline__ int spd_inv_gj(const R *Y, int ld, R *Dinv, int ldi, R * /*col*/, int lane) {
+__device__ __forceinline__ void gj_blocks_to_lds(R v00, R v01, R v10, R v11, R *Dinv, int ldi, int lane) {
+    constexpr int NT = gj_blocks<M>();
+    if (lane < NT) {
+        const int bi = tri_row(lane), bj = lane - bi * (bi + 1) / 2, i0 = 2 * bi, i1 = i0 + 1, l0 = 2 * bj, l1 = l0 + 1;
+        if (i0 < M && l0 < M) { Dinv[i0 * ldi + l0] = v00; Dinv[l0 * ldi + i0] = v00; }
+        if (i0 < M && l1 < M && bi != bj) { Dinv[i0 * ldi + l1] = v01; Dinv[l1 * ldi + i0] = v01; }
+        if (i1 < M && l0 < M) { Dinv[i1 * ldi + l0] = v10; Dinv[l0 * ldi + i1] = v10; }
+        if (i1 < M && l1 < M) { Dinv[i1 * ldi + l1] = v11; Dinv[l1 * ldi + i1] = v11; }
+    }
+}
+
+template <int M, typename R>
+__device__ __forceinline__ int spd_inv_gj(const R *Y, int ld, R *Dinv, int ldi, R *blk, int lane) {
     // Block (2x2 pivots) symmetric Gauss-Jordan sweep: T = ceil(M/2) rounds instead of M; branch-free.
     //   P = A_JJ ;  A_IL -= A_IJ P^-1 A_JL (I,L not J) ;  A_IJ <- A_IJ P^-1 ;  A_JL <- P^-1 A_JL ;  A_JJ <- -P^-1 ;  result = -A^-1
     constexpr int T = (M + 1) / 2, NT = T * (T + 1) / 2;
     static_assert(NT <= 64, "one wave");
-    int bi = 0, rem = min(lane, NT - 1);
-    while (rem > bi) { rem -= bi + 1; bi++; }
-    const int bj = rem;
+    const int lt = min(lane, NT - 1), bi = tri_row(lt), bj = lt - bi * (bi + 1) / 2;
     const bool act = lane < NT;
     const int i0 = 2 * bi, i1 = i0 + 1, l0 = 2 * bj, l1 = l0 + 1;
     // padded (2T x 2T) matrix: identity in the padding row/col when M is odd
@@ -492,11 +518,12 @@ __device__ __forceinline__ int spd_inv_gj(const R *Y, int ld, R *Dinv, int ldi, 
         a00 = fma(a00, m, -fma(t00, cl00, t01 * cl01)); a01 = fma(a01, m, -fma(t00, cl10, t01 * cl11));
         a10 = fma(a10, m, -fma(t10, cl00, t11 * cl01)); a11 = fma(a11, m, -fma(t10, cl10, t11 * cl11));
     }
-    if (act) {   // Dinv = -swept, mirrored to the full matrix
-        if (i0 < M && l0 < M) { Dinv[i0 * ldi + l0] = -a00; Dinv[l0 * ldi + i0] = -a00; }
-        if (i0 < M && l1 < M && bi != bj) { Dinv[i0 * ldi + l1] = -a01; Dinv[l1 * ldi + i0] = -a01; }
-        if (i1 < M && l0 < M) { Dinv[i1 * ldi + l0] = -a10; Dinv[l0 * ldi + i1] = -a10; }
-        if (i1 < M && l1 < M) { Dinv[i1 * ldi + l1] = -a11; Dinv[l1 * ldi + i1] = -a11; }
+    // Dinv = -swept: mirrored to the full matrix in LDS, and (blk != nullptr) the lane's 2x2 block as it is to the block-packed copy in global
+    // memory -- 4 NT doubles per matrix (180 of 289 for M = 17), two 16-byte stores per lane straight from the registers
+    gj_blocks_to_lds<M>(-a00, -a01, -a10, -a11, Dinv, ldi, lane);
+    if (blk != nullptr && act) {
+        if constexpr (sizeof(R) == 8) { st2((double *)blk + 4 * lane, d2{-a00, -a01}); st2((double *)blk + 4 * lane + 2, d2{-a10, -a11}); }
+        else { blk[4 * lane] = -a00; blk[4 * lane + 1] = -a01; blk[4 * lane + 2] = -a10; blk[4 * lane + 3] = -a11; }
     }
     wsync();
     return fail;

@@ -824,8 +824,14 @@ def test_config5_shaped_monte_carlo_1024_seeds_30_steps():
     # manoeuvre); the reference script would carry on the same way (:149-182)
     assert succ.shape == (S, steps) and succ.mean() > 0.7, succ.mean()
     assert np.isfinite(r1["state_trajectory"]).all()
-    nx_ok = r1["nominal_trajectory_x"].transpose(0, 3, 2, 1)[succ]           # (runs x steps solved, N+1, nx)
-    assert (nx_ok[:, 1:] <= m.x_ub + 1e-6).all() and (nx_ok[:, 1:] >= m.x_lb - 1e-6).all()
+    # a solved step leaves stages 1 .. N-1 of its nominal inside the box (both QPs bound x_k + dx_k there).  Not the terminal stage: the tightened QP
+    # bounds dx_N by the RAW gf (quirk q2, fast_SLS_jit.py:524,568), so x_N may sit outside, and after flagged steps -- which shift the nominal and
+    # extrapolate its last stage without a solve -- the whole tail may; the reference's loop does the same, the 2-seed comparison pins it
+    nx_ok = r1["nominal_trajectory_x"].transpose(0, 3, 2, 1)           # (runs, steps, N+1, nx)
+    after_solved = succ.copy(); after_solved[:, 1:] &= succ[:, :-1]
+    inner = nx_ok[after_solved][:, 1:N - 1]
+    viol = np.maximum(inner - m.x_ub, m.x_lb - inner)
+    assert viol.max() <= 1e-6, float(viol.max())
     assert len({r1["state_trajectory"][s].tobytes() for s in range(0, S, 97)}) == len(range(0, S, 97))    # seeds differ
 
 
@@ -992,7 +998,8 @@ def test_wave_level_building_blocks(nx, nu):
 
 def test_infeasible_box_is_flagged_early_by_the_stagnation_rule():
     """A QP whose x_0 is fine but whose box is empty at one stage (upper bound below the lower one) has no solution: the interior point must end
-    flagged (status 1 or 3, never 0 / 4) after a few dozen iterations instead of qp_max_iter = 60, and its neighbours in the batch are untouched."""
+    flagged -- by its Farkas certificate (status 5) or, failing that, the stagnation rule (1 / 3), never 0 / 4 -- well before qp_max_iter = 60
+    iterations, and its neighbours in the batch are untouched."""
     from robust_nonlinear_mpc_amd import BatchedFastSLS, make_batch
     B = 8
     batch = make_batch("quadrotor", os.path.join(GOLDEN, "sweep_quadrotor_N20_s0.npz"), B, seed=5)
@@ -1016,7 +1023,7 @@ def test_infeasible_box_is_flagged_early_by_the_stagnation_rule():
     x, y, st, it, _ = f.qp_solve()
     qs = f.get("qp_stats", (2, 8), np.int32)
     f.close()
-    assert st[2] in (1, 3) and it[2] < 45, (st[2], it[2])
+    assert st[2] in (1, 3, 5) and it[2] < 45, (st[2], it[2])
     assert qs[2, 0, 1] < 110
     ok = [b for b in range(B) if b != 2]
     assert (st[ok] == 0).all() and np.array_equal(x[ok], xr[ok])

@@ -1327,6 +1327,9 @@ __global__ __launch_bounds__(64) void k_selftest(int which, const double *in, do
     else if (which == 4) wla::gemm_mfma<NX, NX, NU, false, false, true>(I0, NU, I0 + NB, NX, O0, NX, lane, I0 + 2 * NB, NX);        // D + Bm K  (in: Bm, K NU x NX, D NX x NX)
     else if (which == 5) wla::gemm_mfma_pair<NU, NX, NX, NX>(I0, NX, I0 + NB, NX, I0 + NB + MM, NX, O0, NX, O0 + NB, NX, lane);     // K P | A P (in: K NU x NX, A, P)
     else if (which == 6) { const int f = wla::spd_inv_gj<NX>(I0, NX, O0, NX, (double *)nullptr, lane); if (lane == 0) O0[MM] = (double)f; }   // inverse of the SPD matrix whose lower triangle is given
+    else if (which == 8) {   // the same inverse by the matrix-core sweep; its block-packed copy (4 x gj_blocks doubles) follows the flag in the output
+        const int f = wla::spd_inv_gj_mfma<NX>(I0, NX, O0, NX, O0 + MM + 1, lane); if (lane == 0) O0[MM] = (double)f;
+    }
     else if (which == 7) {   // lower(Y) = A diag(pix) A' + B diag(piu) B' - T (A diag(pix))' + diag(d) + delta    (in: A, B, T, pix, piu, d)
         const double *A = I0, *Bm = I0 + MM, *T = I0 + MM + NB, *pix = T + MM, *piu = pix + NX, *d = piu + NU;
         if constexpr (NX >= 5) wla::build_Y_mfma<NX, NU>(A, pix, Bm, piu, T, true, d, 1e-13, O0, lane);

@@ -31,6 +31,10 @@ constexpr int ST_INIT = -1;
 #ifndef NE_MFMA
 #define NE_MFMA 1
 #endif
+// NE_GJ_MFMA (default 1): the inverse of D_k by the matrix-core Gauss-Jordan sweep (wla::spd_inv_gj_mfma); 0 = the 2x2-block vector-ALU sweep
+#ifndef NE_GJ_MFMA
+#define NE_GJ_MFMA 1
+#endif
 
 struct Costs {  // batch-constant diagonal weights (device pointers)
     const double *Qd, *Rd, *Qfd;        // diag of Q, R, Qf (P = 2*blkdiag)
@@ -226,7 +230,8 @@ __device__ __forceinline__ int ne_forward(double *sm, const NeG<NX, NU> g, bool 
             else wla::build_Y_lower<NX, NU>(Lcur, sA, sB, sPiS + NX, sL1, k > 0, sPiS + NZ, delta, sY, lane);
             wla::wsync();
             // the inverse goes to LDS (full, for this stage's and the next stage's products) and, block-packed from the registers, to the scratch
-            fail |= wla::spd_inv_gj<NX>(sY, NX, Lcur, NX, g.Linv + (size_t)k * IO::DSTR, lane);
+            if constexpr (Ld::MFMA && NE_GJ_MFMA != 0) fail |= wla::spd_inv_gj_mfma<NX>(sY, NX, Lcur, NX, g.Linv + (size_t)k * IO::DSTR, lane);      // one rank-2 MFMA update per 2x2 pivot
+            else fail |= wla::spd_inv_gj<NX>(sY, NX, Lcur, NX, g.Linv + (size_t)k * IO::DSTR, lane);
         }
         // rhs b = A v_x + B v_u - v_x,k+1 - eflag e_k  (+ A (pi_x,k .* Linv_{k-1}' w_{k-1}))
         // t_k = A (v_x + pi_x,k .* u_{k-1}) + B v_u - v_x,k+1 - eflag e_k   (u_{k-1} = Dinv_{k-1} t_{k-1} kept in sWp; the second term is -O_k u_{k-1})

@@ -157,6 +157,7 @@ __device__ __forceinline__ void gemm_mfma(const double *A, int lda, const double
                                           int ldd = 0, const double *sk = nullptr) {
     static_assert(M <= 17 && N <= 17 && K <= 17, "one 16x16 tile plus one border row / column / k");
     constexpr int MC = M < 16 ? M : 16, NC = N < 16 ? N : 16, KC = K < 16 ? K : 16;
+    asm volatile("" : "+v"(lane));      // indices derived from the lane id are recomputed per call, not hoisted out of the caller's loops and kept live (see spd_inv_gj_mfma)
     const int li = lane & 15, lk = lane >> 4;
     auto a_at = [&](int i, int k) -> double { const double v = TA ? A[k * lda + i] : A[i * lda + k]; return SCALEK ? v * sk[k] : v; };
     auto b_at = [&](int k, int j) -> double { return TB ? B[j * ldb + k] : B[k * ldb + j]; };
@@ -326,6 +327,7 @@ __device__ __forceinline__ void build_Y_mfma(const double *A, const double *pix,
                                              const double *d, double delta, double *Y, int lane) {
     static_assert(NX >= 5 && NX <= 17 && NU <= 4, "one 16x16 tile");
     constexpr int MC = NX < 16 ? NX : 16;
+    asm volatile("" : "+v"(lane));      // indices derived from the lane id are recomputed per call, not hoisted out of the caller's loops and kept live (see spd_inv_gj_mfma)
     const int li = lane & 15, lk = lane >> 4, lc = min(li, MC - 1);
     mfma_d4 acc;
 #pragma unroll
@@ -527,6 +529,93 @@ __device__ __forceinline__ int spd_inv_gj(const R *Y, int ld, R *Dinv, int ldi, 
     }
     wsync();
     return fail;
+}
+
+// The same symmetric Gauss-Jordan sweep with 2x2 pivots for 13 <= M <= 17 on the fp64 matrix core.  The 16x16 core of the matrix lives in the
+// accumulator layout of v_mfma_f64_16x16x4_f64 (lane l: column l & 15, rows (l >> 4) + 4 r), row / column 16 of a 17 x 17 matrix in one value per
+// lane plus the corner.  One round = one rank-2 update of the whole tile:  A <- m o A - (C P^-1) C'  with C the two pivot columns -- which, the
+// matrix being symmetric, are the two pivot ROWS: lane (col, .) fetches rows 2jb, 2jb+1 at its column from the accumulators of two other lanes
+// (two crossbar gathers; the 2x2-block version needs eight), forms its entries of both operands from them, zeroes its accumulators in the pivot
+// rows / columns (the -I substitution of spd_inv_gj makes the one update produce C P^-1, P^-1 C' and -P^-1 there) and issues ONE MFMA.  The border
+// row follows with two fused multiply-adds per lane, the last round pivots on the corner.  ~620 instead of ~1 090 instructions for M = 17, same
+// pivots, same formulas; sums inside a rank-2 update are associated differently (last-bit differences).  Needs all 64 lanes.
+// Y: lower triangle in LDS (ld); Dinv: full symmetric M x M in LDS (ldi); blk (optional): block-packed copy in global memory as spd_inv_gj writes it.
+template <int M>
+__device__ __forceinline__ int spd_inv_gj_mfma(const double *Y, int ld, double *Dinv, int ldi, double *blk, int lane) {
+    static_assert(M >= 9 && M <= 17, "one 16x16 tile plus one border row");
+    constexpr int MC = M < 16 ? M : 16, RT = (MC + 1) / 2;
+    constexpr bool BORDER = (M == 17);
+    // (the lane id is laundered: the per-round 0 / 1 masks below are functions of it alone, and a caller's stage loop would otherwise have all of
+    // them hoisted out and kept live across its whole body -- 60+ registers, spilled)
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, lk = lane >> 4;
+    mfma_d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = lk + 4 * r, hi = max(row, li), lo = min(row, li);
+        const double v = Y[min(hi, MC - 1) * ld + min(lo, MC - 1)];
+        acc[r] = (hi < MC) ? v : ((row == li) ? 1.0 : 0.0);           // identity in the padding of a tile that is not full
+    }
+    double bd = 0.0, corner = 0.0;                                      // row 16: entry (16, li) on every lane; the corner (16, 16)
+    if constexpr (BORDER) { bd = Y[16 * ld + li]; corner = Y[16 * ld + 16]; }
+    // selections as products with 0 / 1 (one instruction per double instead of two v_cndmask_b32; every value involved is finite)
+    const double m0 = (lk == 0) ? 1.0 : 0.0, m1 = (lk == 1) ? 1.0 : 0.0;      // the lane groups that feed k = 0 / k = 1 of the rank-2 update
+    double dmin = 1.0;            // smallest pivot seen (a pivot that is not positive is clamped; reported once at the end)
+#pragma unroll
+    for (int jb = 0; jb < RT; jb++) {
+        const int pk0 = 2 * jb, pk1 = pk0 + 1, rp = pk0 / 4, g0 = pk0 % 4, g1 = pk1 % 4;      // both pivot rows sit in accumulator rp, lane groups g0, g1
+        const double src = acc[rp];
+        double c0 = bperm_d(src, li + 16 * g0), c1 = bperm_d(src, li + 16 * g1);                // rows pk0, pk1 at column li
+        double e0 = 0.0, e1 = 0.0;
+        if constexpr (BORDER) { e0 = readlane_d(bd, pk0); e1 = readlane_d(bd, pk1); }           // (16, pk0), (16, pk1)
+        __builtin_amdgcn_sched_barrier(0);
+        const double pa = readlane_d(src, pk0 + 16 * g0), pb = readlane_d(src, pk0 + 16 * g1), pc = readlane_d(src, pk1 + 16 * g1);
+        const double d1 = fmax(pa, tiny_pivot<double>());                                        // (fmax also maps NaN to the clamp)
+        const double r1 = fast_rcp(d1), bp = pb * r1;
+        const double d2r = fma(-pb, bp, pc), d2 = fmax(d2r, tiny_pivot<double>());
+        dmin = fmin(dmin, fmin(pa == pa ? pa : -1.0, d2r == d2r ? d2r : -1.0));
+        const double r2 = fast_rcp(d2);
+        const double q11 = r2, q01 = -bp * r2, q00 = fma(bp * bp, r2, r1);                      // P^-1 = [[q00, q01],[q01, q11]]
+        const double j0 = (li == pk0) ? 1.0 : 0.0, j1 = (li == pk1) ? 1.0 : 0.0, keep = 1.0 - j0 - j1;     // column li in the pivot block?
+        c0 = fma(c0, keep, -j0);                                                                // pivot rows / columns send -I
+        c1 = fma(c1, keep, -j1);
+        const double t0 = fma(c0, q00, c1 * q01), t1 = fma(c0, q01, c1 * q11);                  // row li of C P^-1
+        const double av = fma(t0, m0, t1 * m1), bv = fma(c0, m0, c1 * m1);
+        const double keepr = keep * (((lk == g0) | (lk == g1)) ? 0.0 : 1.0);                    // accumulator rp also holds the pivot ROWS
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] *= (r == rp) ? keepr : keep;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, bv, acc, 0, 0, 0);
+        if constexpr (BORDER) {
+            const double u0 = fma(e0, q00, e1 * q01), u1 = fma(e0, q01, e1 * q11);              // (16, J) P^-1
+            bd = fma(bd, keep, -fma(u0, c0, u1 * c1));
+            corner -= fma(u0, e0, u1 * e1);
+        }
+    }
+    if constexpr (BORDER) {      // last round: the 1x1 pivot (16, 16)
+        const double d = fmax(corner, tiny_pivot<double>());
+        dmin = fmin(dmin, corner == corner ? corner : -1.0);
+        const double q = fast_rcp(d), t = bd * q;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-t * m0, bd * m0, acc, 0, 0, 0);
+        bd = t; corner = -q;
+    }
+    // Dinv = -swept.  The two triangles of the tile were updated by separate MFMA lanes and differ in the last bit: the lower one is mirrored, so
+    // that the matrix in LDS is exactly symmetric and equal to what the block-packed copy gives back
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int row = lk + 4 * r; if (row < MC && li <= row) { Dinv[row * ldi + li] = -acc[r]; Dinv[li * ldi + row] = -acc[r]; } }
+    if constexpr (BORDER) {
+        if (lk == 0) { Dinv[16 * ldi + li] = -bd; Dinv[li * ldi + 16] = -bd; }
+        if (lane == 0) Dinv[16 * ldi + 16] = -corner;
+    }
+    wsync();
+    if (blk != nullptr) {       // the block-packed copy for the solve-only sweeps (layout of spd_inv_gj / gj_blocks_to_lds)
+        constexpr int NT = gj_blocks<M>();
+        if (lane < NT) {
+            const int bi = tri_row(lane), bj = lane - bi * (bi + 1) / 2, i0 = 2 * bi, i1 = min(i0 + 1, M - 1), l0 = 2 * bj, l1 = min(l0 + 1, M - 1);
+            st2(blk + 4 * lane, d2{Dinv[i0 * ldi + l0], Dinv[i0 * ldi + l1]});
+            st2(blk + 4 * lane + 2, d2{Dinv[i1 * ldi + l0], Dinv[i1 * ldi + l1]});
+        }
+    }
+    return (dmin > tiny_pivot<double>()) ? 0 : 1;
 }
 
 // Solve the small SPD system H z = f (NU x NU, H in LDS broadcast) redundantly per lane; f/z in registers.

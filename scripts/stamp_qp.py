@@ -16,6 +16,9 @@ cl.reset(np.tile(x0, (B, 1)), solve_nominal=True, continuation=2 if scale > 0.6 
 for i in range(steps):
     cl.step(W[i], fetch=False)
     kk = cl.f.get("kkt", (8,)); qs = cl.f.get("qp_stats", (2, 8), np.int32)
+    if not (kk[:, 7] > 0).any():
+        continue
+    kk, qs = kk[kk[:, 7] > 0], qs[kk[:, 7] > 0]
     tot = kk[:, 7].mean()
     print(f"step {i} QP2: ticks {qs[:,1,1].mean():.2f} factor stages {kk[:,3].mean():.1f} | cycles/instance total {tot:.0f}: fwd-factor {kk[:,2].mean()/tot:.2f} fwd-solve {kk[:,4].mean()/tot:.2f} "
           f"bwd {kk[:,5].mean()/tot:.2f} phase {kk[:,6].mean()/tot:.2f} | per factorised stage {kk[:,2].sum()/max(1,kk[:,3].sum()):.0f} cyc, per bwd sweep {kk[:,5].sum()/qs[:,1,1].sum():.0f}, per phase {kk[:,6].sum()/qs[:,1,1].sum():.0f}", flush=True)

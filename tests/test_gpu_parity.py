@@ -697,10 +697,10 @@ def test_script_regime_64_seeds_30_steps_every_qp_certified_or_flagged():
     assert (ran & np.isin(st, (1, 3))).sum() <= 2, np.argwhere(ran & np.isin(st, (1, 3)))
     assert (st[ran] != 4).mean() > 0.99                             # solved means certified, not merely interior-point accurate
     assert ran[:, :, 0].mean() > 0.85 and r1["success"].mean() > 0.7, (ran[:, :, 0].mean(), r1["success"].mean())
-    # independent certificate of every tightened QP reported certified: stationarity and multiplier signs 1e-8 |q|inf, complementarity 1e-7 |q|inf, primal
+    # independent certificate of every tightened QP reported certified: stationarity and multiplier signs 1e-8 |q|inf, complementarity 1e-6 |q|inf, primal
     # residual (dynamics rows and boxes, absolute) 1e-6 -- the tolerance the in-kernel certificate allows the dynamics rows
     assert r1["kkt_checked"] > 0.6 * S * steps, r1["kkt_checked"]
-    assert (r1["kkt_worst"] < np.array([1e-8, 1e-6, 1e-8, 1e-7])).all(), r1["kkt_worst"]
+    assert (r1["kkt_worst"] < np.array([1e-8, 1e-6, 1e-8, 1e-6])).all(), r1["kkt_worst"]
     assert np.isfinite(r1["x"]).all() and len({r1["x"][-1, s].tobytes() for s in range(S)}) == S      # seeds differ
 
 
@@ -988,6 +988,24 @@ def test_wave_level_building_blocks(nx, nu):
     # a matrix that is not positive definite is reported (pivot clamped, flag set)
     Yb = Y.copy(); Yb[nx // 2, nx // 2] = -1.0
     assert run(6, [np.tril(Yb)], MM + 1)[MM] != 0.0
+    # the same inverse by the matrix-core Gauss-Jordan sweep (one rank-2 MFMA update per 2x2 pivot), and its block-packed copy: lane (bi >= bj) of
+    # the lower-triangular 2x2 block grid holds rows {2bi, 2bi+1} x columns {2bj, 2bj+1}
+    T2 = (nx + 1) // 2
+    nblk = T2 * (T2 + 1) // 2
+    o = run(8, [np.tril(Y)], MM + 1 + 4 * nblk)
+    assert o[MM] == 0.0
+    Dm = o[:MM].reshape(nx, nx)
+    assert np.array_equal(Dm, Dm.T)
+    assert np.max(np.abs(Dm @ Y - np.eye(nx))) < 1e-15 * np.linalg.cond(Y) * nx
+    assert np.max(np.abs(Dm - Di)) < 1e-15 * np.linalg.cond(Y) * nx * np.abs(Di).max()
+    blocks = o[MM + 1:].reshape(nblk, 2, 2)
+    lane = 0
+    for bi in range(T2):
+        for bj in range(bi + 1):
+            rows, cols = [2 * bi, min(2 * bi + 1, nx - 1)], [2 * bj, min(2 * bj + 1, nx - 1)]
+            assert np.array_equal(blocks[lane], Dm[np.ix_(rows, cols)]), (bi, bj)
+            lane += 1
+    assert run(8, [np.tril(Yb)], MM + 1 + 4 * nblk)[MM] != 0.0
     # D_k assembly: lower triangle of  M1 A' + B diag(piu) B' - T M1' + diag(d) + delta,  M1 = A diag(pix)
     T = rng.normal(size=(nx, nx)); pix, piu, d = rng.uniform(0.1, 2.0, nx), rng.uniform(0.1, 2.0, nu), rng.uniform(0.1, 2.0, nx)
     M1 = A * pix[None, :]

@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 FIXTURE = {"rocket": "sweep_rocket_N20_s0.npz", "quadrotor": "sweep_quadrotor_N20_s0.npz", "pendulum": "sweep_pendulum_N10_s0.npz"}
 QP_BYTES = {"rocket": 93656, "quadrotor": 64504, "pendulum": 6112}     # algorithmic bytes per QP solve
+SWEEP_BYTES = {"rocket": 344000, "quadrotor": 190000, "pendulum": 12000}  # ... per SLS sweep: A, B, eta, eta_f in; beta, beta_f, back-offs out (rocket 197 + 147 KB)
 SWEEP_MFLOP = 9.0                                                      # per rocket N=20 instance, scaled with nx^3 N^2 otherwise
 X0_SCALE = {"rocket": 1.0, "quadrotor": 1.0, "pendulum": 1.0}      # 1.0 = the script's own initial state
 X0_SCALE_SECONDARY = 0.3                                               # round 2's headline regime, kept as a labelled secondary figure
@@ -396,12 +397,15 @@ def main():
     per_sweep_bytes = 8 * (N * m.nx * nz + 2 * n_var + N * m.nx)
     kf, ks = 28.6e3 * (m.nx / 17.0) ** 3, 2.0e3 * (m.nx / 17.0) ** 2
 
-    def roof_block(ms_total, launches, inst_sweeps, factor_stages, qp_solves):
+    sweep_flop = SWEEP_MFLOP * 1e6 * (m.nx / 17.0) ** 3 * (N / 20.0) ** 2
+
+    def roof_block(ms_total, launches, inst_sweeps, factor_stages, qp_solves, sls_sweeps=0):
+        """sls_sweeps > 0: the launches are fused RTI chains (k_rti_chain) that also ran that many SLS sweeps (9.0 Mflop per rocket instance)."""
         L = max(1, launches)
         ms = ms_total / L
-        flops = (factor_stages * kf + 2.0 * inst_sweeps * N * ks) / L
+        flops = (factor_stages * kf + 2.0 * inst_sweeps * N * ks + sls_sweeps * sweep_flop) / L
         tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        alg = QP_BYTES[args.model] * float(qp_solves) / L
+        alg = (QP_BYTES[args.model] * float(qp_solves) + SWEEP_BYTES[args.model] * float(sls_sweeps)) / L
         work = per_sweep_bytes * float(inst_sweeps) / L
         return {"achieved": tf, "frac": tf / 78.6, "avg_launch_ms": ms, "launches": launches, "flops_per_launch": flops,
                 "qp_solves_per_launch": float(qp_solves) / L, "block_solves_per_qp": float(inst_sweeps) / max(1, qp_solves),
@@ -493,18 +497,24 @@ def main():
         out["config"]["last_qp_certified_frac"] = float(np.mean(st == 0))
         # dominant kernel: k_qp_solve; time = HIP events around every launch on the launching stream (opts.time_kernels), work = device counters.
         # The kernel is bound by vector-ALU instruction issue: its roof is the fp64 peak (matrix = vector = 78.6 TFLOP/s).
-        rb = roof_block(k_ms, k_launches, inst_sweeps, fact_stages, qp_solves)
+        # rocket script setting (rti = 1, one fast-SLS step) in fp64: the whole RTI solve of an instance is ONE launch (k_rti_chain: QP -> eta -> Riccati /
+        # propagation -> tightened bounds -> QP), the timed launches are those and their work includes the SLS sweeps of the instances whose first QP solved
+        fused = (args.workload == "closed_loop" and m.fast_sls_rti_steps == 1 and args.precision == 0 and int(os.environ.get("QP_FUSE_RTI", "1")) != 0
+                 and int(os.environ.get("SLSQP_FUSE_RTI", "1")) != 0)
+        sls_sweeps = int(sum(int(np.isin(st_[:, 0, 6], (0, 4)).sum()) for st_ in per_step)) if fused else 0
+        dom_kernel = "k_rti_chain" if fused else "k_qp_solve"
+        rb = roof_block(k_ms, k_launches, inst_sweeps, fact_stages, qp_solves, sls_sweeps)
         # HBM traffic from PMC counters: attached only when the committed passes were taken on exactly this command
         command = bench_command(args, n_sl, x0_scale)
-        traffic, tsrc = read_traffic("pmc_traffic.json", "k_qp_solve_bytes_per_launch", command)
+        traffic, tsrc = read_traffic("pmc_traffic.json", dom_kernel + "_bytes_per_launch", command)
         calls = args.steps * n_sl
-        sweep_flop = SWEEP_MFLOP * 1e6 * (m.nx / 17.0) ** 3 * (N / 20.0) ** 2
         step_tf = (fact_stages * kf + 2.0 * inst_sweeps * N * ks + args.steps * B * sweep_flop) / dt / 1e12
-        out["roofline"] = dict({"bound": "mfma", "kernel": "k_qp_solve", "peak": 78.6, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": tsrc}, **rb)
+        out["roofline"] = dict({"bound": "mfma", "kernel": dom_kernel, "peak": 78.6, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": tsrc}, **rb)
         out["roofline"].update({
             "note": "fp64: matrix peak = vector peak on MI355X; the kernel issues its block products on the matrix core and is bound by vector-ALU issue",
             "qp_solve": {"avg_ms": sum(a["qp"] for a in acc) / (qp_per_inst * calls), "instances": B / n_sl,
-                         "note": "one solve call = one slice; slices run concurrently, so these times overlap"},
+                         "note": ("fused chain: (launch duration - the sweep part as instance 0 spent it in the kernel) / 2" if fused else "one solve call = one slice") +
+                                 "; slices run concurrently, so these times overlap"},
             # the whole step: fp64 work of the timed region (QP kernel + 9.0 Mflop per rocket instance for the SLS sweep) over wall time
             "whole_step_fp64": {"achieved_TFLOPs": step_tf, "peak_TFLOPs": 78.6, "frac": step_tf / 78.6},
             "sweep_avg_launch_ms": sum(a["sweep"] for a in acc) / calls, "slice_gpu_ms_per_step": [round(a["total"] / args.steps, 2) for a in acc]})
@@ -540,8 +550,8 @@ def main():
                     ms1, n1, sw1, _ = one.kernel_timing()
                     fs1, qs1 = one.factor_stages, one.qp_solves
                     one.close()
-                    tr1, ts1 = read_traffic("pmc_traffic_single_slice.json", "k_qp_solve_bytes_per_launch", bench_command(args, 1, x0_scale))
-                    out["roofline"]["single_slice"] = dict(roof_block(ms1, n1, sw1, fs1, qs1), traffic=tr1, traffic_source=ts1, ms_per_step=1e3 * dt1 / args.steps,
+                    tr1, ts1 = read_traffic("pmc_traffic_single_slice.json", dom_kernel + "_bytes_per_launch", bench_command(args, 1, x0_scale))
+                    out["roofline"]["single_slice"] = dict(roof_block(ms1, n1, sw1, fs1, qs1, sls_sweeps), traffic=tr1, traffic_source=ts1, ms_per_step=1e3 * dt1 / args.steps,
                                                            gpu_ms_per_step={k: a1[0][k] / args.steps for k in a1[0]},
                                                            note="same closed-loop steps with the whole batch as one slice, after the timed region")
             except Exception as e:      # never lose the headline line to an auxiliary measurement

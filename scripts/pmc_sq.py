@@ -2,6 +2,7 @@
 count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles (MI355X_MICROARCH.md, constants table)."""
 import collections, csv, glob, json, sys
 src, dst = sys.argv[1], sys.argv[2]
+cmd = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py --no-cpu --no-secondary --slices 1"
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(set)
 for f in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
@@ -24,7 +25,7 @@ for k, v in acc.items():
     if bc > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
         d["mfma_busy_cycles_per_sq_busy_cycle"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / bc
     out[k] = d
-json.dump({"source": "rocprofv3 --pmc (one SQ pass), command: python3 bench.py --steps 5 --warmup 1 --no-cpu --no-secondary --slices 1", "kernels": out}, open(dst, "w"), indent=1)
-for k in ("k_qp_solve", "k_sweep_prop", "k_sweep_ric1", "k_lin_tan", "k_lin_val"):
+json.dump({"source": "rocprofv3 --pmc (one SQ pass), command: " + cmd, "kernels": out}, open(dst, "w"), indent=1)
+for k in ("k_rti_chain", "k_qp_solve", "k_sweep_prop", "k_sweep_ric1", "k_lin_tan", "k_lin_val"):
     if k in out:
         print(k, {a: (round(b, 4) if isinstance(b, float) and b < 10 else b) for a, b in out[k].items()})

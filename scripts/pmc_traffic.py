@@ -6,6 +6,9 @@ src, dst = sys.argv[1], sys.argv[2]
 build = sys.argv[3] if len(sys.argv) > 3 else "?"
 cmd = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 2 --warmup 1 --no-cpu --no-secondary"
 tail_n = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # the bench's timed region = the last tail_n launches of the dominant kernel
+slices = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+extra = sys.argv[7:]                                         # further bench flags the passes ran with (none for the default command)
+DOM = "k_rti_chain"
 per_disp = collections.defaultdict(lambda: collections.defaultdict(dict))
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
@@ -21,17 +24,21 @@ for k, v in acc.items():
     fetch, write = v.get("FETCH_SIZE", 0.0) * 1024 / nf, v.get("WRITE_SIZE", 0.0) * 1024 / nw
     out[k] = {"launches": nf, "fetch_bytes_per_launch_raw": fetch, "fetch_bytes_per_launch_x2": 2 * fetch, "write_bytes_per_launch": write}
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), command: " + cmd, "build": build, "kernels": out}
-for kn in ("k_qp_solve", "k_sweep_prop", "k_sweep_ric1", "k_lin_tan"):
+if not extra:      # the default bench command: what bench.py's bench_command() must equal for the figure to be attached to a bench line
+    res["command"] = {"model": "rocket", "batch": 4096, "steps": 30, "warmup": 1, "slices": slices, "x0_scale": 1.0, "precision": 0, "workload": "closed_loop"}
+if DOM not in out:
+    DOM = "k_qp_solve"
+for kn in ("k_rti_chain", "k_qp_solve", "k_sweep_prop", "k_sweep_ric1", "k_lin_tan"):
     if kn in out:
         res[kn + "_bytes_per_launch"] = out[kn]["fetch_bytes_per_launch_x2"] + out[kn]["write_bytes_per_launch"]
-if tail_n > 0 and "k_qp_solve" in per_disp:
-    # same launches as bench.py's roofline averages: the last tail_n dispatches of k_qp_solve (the earlier ones belong to the untimed set-up)
+if tail_n > 0 and DOM in per_disp:
+    # same launches as bench.py's roofline averages: the last tail_n dispatches of the dominant kernel (the earlier ones belong to the untimed set-up / warm-up)
     tot = 0.0
     for cn, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-        dd = per_disp["k_qp_solve"].get(cn, {})
+        dd = per_disp[DOM].get(cn, {})
         last = sorted(dd)[-tail_n:]
         tot += mult * 1024.0 * sum(dd[i] for i in last) / max(1, len(last))
-    res["k_qp_solve_bytes_per_launch_timed_region"] = tot
+    res[DOM + "_bytes_per_launch_timed_region"] = tot
     res["timed_region_launches"] = tail_n
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps(res)[:1500])

@@ -527,8 +527,8 @@ def main():
         dev.close()
         if args.workload == "closed_loop" and not args.no_cpu:
             try:
-                # QPs sampled ACROSS the timed steps: the first 32 seeds of rank 0, every third closed-loop step
-                ns, every = min(32, B), 3
+                # QPs sampled ACROSS the timed steps: the first 128 seeds of rank 0, every third closed-loop step (~1000 MPC steps: 20-30 s of CPU work)
+                ns, every = min(128, B), 3
                 cpu_data, taken = sample_qp_data(m, N, seeds[:ns], x0, cont, args.steps, every, local_rank, tune, ClosedLoopSlices)
                 cpu_sample = (f"the MPC steps of seeds {int(seeds[0])}..{int(seeds[ns - 1])} at closed-loop steps {[t for t, _ in taken]} of the timed run whose two QPs the GPU "
                               f"solved ({[c for _, c in taken]} instances per step; the steps interleaved)")

@@ -7,7 +7,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(set)
 for f in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]
+        k = r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0].replace("void ", "").strip()
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[k].add(r["Dispatch_Id"])
 out = {}

@@ -14,7 +14,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = c
 for f in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-            k = r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]
+            k = r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0].replace("void ", "").strip()
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]].add(r["Dispatch_Id"])
             d = per_disp[k][r["Counter_Name"]]
             d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])

@@ -525,15 +525,6 @@ def main():
                         "x0_arg": batch["x0_arg"][:ncpu]}
             cpu_sample = f"the first {ncpu} synthetic instances of rank 0"
         dev.close()
-        if args.workload == "closed_loop" and not args.no_cpu:
-            try:
-                # QPs sampled ACROSS the timed steps: the first 128 seeds of rank 0, every third closed-loop step (~1000 MPC steps: 20-30 s of CPU work)
-                ns, every = min(128, B), 3
-                cpu_data, taken = sample_qp_data(m, N, seeds[:ns], x0, cont, args.steps, every, local_rank, tune, ClosedLoopSlices)
-                cpu_sample = (f"the MPC steps of seeds {int(seeds[0])}..{int(seeds[ns - 1])} at closed-loop steps {[t for t, _ in taken]} of the timed run whose two QPs the GPU "
-                              f"solved ({[c for _, c in taken]} instances per step; the steps interleaved)")
-            except Exception as e:
-                cpu_data, cpu_sample = None, repr(e)
         if not args.no_secondary and world == 1:
             try:
                 # the same kernels with the whole batch in ONE slice (no concurrent launches) after the timed region: with several slices the HIP-event
@@ -593,6 +584,15 @@ def main():
                                                   "certified_frac": float(np.mean(sst == 0)), "steps": 3, "slices": args.slices}
                 except Exception as e:
                     out["secondary_synthetic"] = {"error": repr(e)}
+        if args.workload == "closed_loop" and not args.no_cpu:
+            try:
+                # QPs sampled ACROSS the timed steps: the first 128 seeds of rank 0, every third closed-loop step (~1000 MPC steps: 20-30 s of CPU work)
+                ns, every = min(128, B), 3
+                cpu_data, taken = sample_qp_data(m, N, seeds[:ns], x0, cont, args.steps, every, local_rank, tune, ClosedLoopSlices)
+                cpu_sample = (f"the MPC steps of seeds {int(seeds[0])}..{int(seeds[ns - 1])} at closed-loop steps {[t for t, _ in taken]} of the timed run whose two QPs the GPU "
+                              f"solved ({[c for _, c in taken]} instances per step; the steps interleaved)")
+            except Exception as e:
+                cpu_data, cpu_sample = None, repr(e)
         if cpu_data is not None and cpu_data["A"].shape[0] > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline(m, N, cpu_data, cpu_sample, args.cpu_budget)

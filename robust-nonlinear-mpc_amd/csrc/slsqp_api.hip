@@ -132,8 +132,8 @@ extern "C" int slsqp_qp_nnz(const slsqp_dims *d, int *n, int *m, int *nnzP, int 
 extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device) {
     if (!supported_dims(d->nx, d->nu)) { fail("unsupported (nx,nu): this build instantiates the kernels for" + dims_list() + " (add pairs with -DSLSQP_EXTRA_DIMS)"); return nullptr; }
     if (d->ni < 1 || d->ni_f < 1 || d->ni > 4096 || d->ni_f > 4096) { fail("need 1 <= ni, ni_f <= 4096"); return nullptr; }
-    if (d->nw != d->nx) { fail("nw must equal nx"); return nullptr; }
-    if (d->N < 1 || d->N > 32 || batch < 1) { fail("need 1 <= N <= 32 and batch >= 1"); return nullptr; }
+    if (d->nw < 1 || d->nw > d->nx) { fail("need 1 <= nw <= nx (E is kept zero-padded to nx columns: the padding adds nothing to any row norm of Phi)"); return nullptr; }
+    if (d->N < 1 || d->N > 64 || batch < 1) { fail("need 1 <= N <= 64 and batch >= 1"); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fail("no HIP device visible: libslsqp_hip has no CPU fallback"); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
@@ -144,7 +144,8 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     const size_t B = batch;
     if (hipStreamCreate(&h->st) != hipSuccess) { fail("hipStreamCreate"); delete h; return nullptr; }
     int rc = 0;
-    rc |= dalloc(h->owned, &h->A, B * N * nx * nx); rc |= dalloc(h->owned, &h->Bm, B * N * nx * nu); rc |= dalloc(h->owned, &h->E, (size_t)(N + 1) * nx * nw);
+    rc |= dalloc(h->owned, &h->A, B * N * nx * nx); rc |= dalloc(h->owned, &h->Bm, B * N * nx * nu); rc |= dalloc(h->owned, &h->E, (size_t)(N + 1) * nx * nx);     // (N+1, nx, nx): E (N+1, nx, nw) zero-padded to nx columns
+    (void)nw;
     rc |= dalloc(h->owned, &h->g, B * N * ni); rc |= dalloc(h->owned, &h->gN, B * nif); rc |= dalloc(h->owned, &h->c, B * N * nx); rc |= dalloc(h->owned, &h->q, B * h->n);
     rc |= dalloc(h->owned, &h->x0val, B * nx); rc |= dalloc(h->owned, &h->gf_raw, (size_t)nif); rc |= dalloc(h->owned, &h->g_raw, (size_t)ni);
     rc |= dalloc(h->owned, &h->Xn, B * (N + 1) * nx); rc |= dalloc(h->owned, &h->Un, B * N * nu); rc |= dalloc(h->owned, &h->xmeas, B * nx); rc |= dalloc(h->owned, &h->x0arg, B * nx);
@@ -256,6 +257,30 @@ static double *stage_buf(slsqp_handle *h, size_t bytes) {
     return h->stage;
 }
 
+// E (N+1, nx, nw), nw <= nx, into the handle's (N+1, nx, nx) buffer: Phi_x[j,j] = E_j (fast_SLS_jit.py:104-108) with nw < nx (dyn/LTV.py:17-32
+// allows any nw) propagates as an nx x nx block whose last nx - nw columns are and stay zero -- every row norm, hence beta, the back-offs and
+// cost_tube, is the one of the nx x nw block.
+__global__ void k_pad_cols(int rows, int nw, int nx, const double *src, double *dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * nx; i += gridDim.x * blockDim.x) { const int r = i / nx, c = i % nx; dst[i] = c < nw ? src[r * nw + c] : 0.0; }
+}
+static int put_E(slsqp_handle *h, const double *E, int loc) {
+    if (!E) return 0;
+    const slsqp_dims &d = h->d;
+    const size_t rows = (size_t)(d.N + 1) * d.nx;
+    if (d.nw == d.nx) return put(h, h->E, E, sizeof(double) * rows * d.nx, loc);
+    const double *src = E;
+    if (loc == SLSQP_HOST) {
+        double *tmp = stage_buf(h, sizeof(double) * rows * d.nw);
+        if (!tmp) return -1;
+        HIPCHK(hipMemcpyAsync(tmp, E, sizeof(double) * rows * d.nw, hipMemcpyHostToDevice, h->st));
+        src = tmp;
+    }
+    hipLaunchKernelGGL(k_pad_cols, dim3(64), dim3(256), 0, h->st, (int)rows, d.nw, d.nx, src, h->E);
+    HIPCHK(hipGetLastError());
+    if (loc == SLSQP_HOST) HIPCHK(hipStreamSynchronize(h->st));
+    return 0;
+}
+
 static bool is_diag(const double *M, int n) {
     for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) if (i != j && M[i * n + j] != 0.0) return false;
     return true;
@@ -306,7 +331,7 @@ extern "C" int slsqp_update_dynamics(slsqp_handle *h, const double *A, const dou
     if (!A || !Bm || !g || !g_N || !c) return fail("A, B, g, g_N, c are required");
     if (put(h, h->A, A, sizeof(double) * B * d.N * d.nx * d.nx, loc)) return -1;
     if (put(h, h->Bm, Bm, sizeof(double) * B * d.N * d.nx * d.nu, loc)) return -1;
-    if (put(h, h->E, E, sizeof(double) * (d.N + 1) * d.nx * d.nw, loc)) return -1;
+    if (put_E(h, E, loc)) return -1;
     if (put(h, h->g, g, sizeof(double) * B * d.N * d.ni, loc)) return -1;
     if (put(h, h->gN, g_N, sizeof(double) * B * d.ni_f, loc)) return -1;
     if (put(h, h->c, c, sizeof(double) * B * d.N * d.nx, loc)) return -1;
@@ -969,7 +994,7 @@ extern "C" int slsqp_set_model(slsqp_handle *h, int model_id, const double *g_ra
     hipSetDevice(h->dev);
     if (h->general_G) return fail("general G: the plants of slsqp_set_model have box constraints");
     const int want_nx = model_id == 0 ? 4 : (model_id == 1 ? 13 : (model_id == 2 ? 17 : -1));
-    if (want_nx != h->d.nx) return fail("model id does not match the handle's dimensions (0 pendulum, 1 quadrotor, 2 rocket)");
+    if (want_nx != h->d.nx || h->d.nw != h->d.nx) return fail("model id does not match the handle's dimensions (0 pendulum, 1 quadrotor, 2 rocket; nw = nx)");
     HIPCHK(hipMemcpy(h->g_raw, g_raw, sizeof(double) * h->d.ni, hipMemcpyHostToDevice));
     h->model_id = model_id;
     return 0;
@@ -977,7 +1002,7 @@ extern "C" int slsqp_set_model(slsqp_handle *h, int model_id, const double *g_ra
 
 extern "C" int slsqp_set_E(slsqp_handle *h, const double *E, int loc) {
     hipSetDevice(h->dev);
-    return put(h, h->E, E, sizeof(double) * (h->d.N + 1) * h->d.nx * h->d.nw, loc);
+    return put_E(h, E, loc);
 }
 
 static int linearize_impl(slsqp_handle *h, const double *X, const double *U, int loc, const int *run) {

@@ -158,7 +158,7 @@ def random_traj(m, x_ref, u_ref, N, rng, amp):
     return X, U
 
 
-def sweep_case(F, name, N, seed, general_G=False):
+def sweep_case(F, name, N, seed, general_G=False, nw_cols=None):
     m, Q, R, Qf, regs, x_ref, u_ref = model_setup(name)
     rng = np.random.default_rng(seed)
     nx, nu, nw = m.nx, m.nu, m.nw
@@ -176,6 +176,9 @@ def sweep_case(F, name, N, seed, general_G=False):
         Gf = np.asarray(m.Gf, dtype=float)
         ni, ni_f = m.ni, m.ni_f
     E = np.stack([np.asarray(m.E, dtype=float)] * (N + 1))
+    if nw_cols is not None:      # fewer disturbance channels than states (dyn/LTV.py:17-32 takes any nw): dense nx x nw blocks that differ per stage
+        nw = int(nw_cols)
+        E = np.stack([np.asarray(m.E, dtype=float)[:, :nw] + 0.01 * rng.normal(size=(nx, nw)) for _ in range(N + 1)])
     eta = np.zeros((N, N, ni))
     for k in range(N):
         for j in range(k + 1):
@@ -312,9 +315,10 @@ def main():
         ("pendulum", 10, 0, False), ("pendulum", 10, 1, True), ("pendulum", 3, 2, False),
         ("quadrotor", 20, 0, False), ("rocket", 20, 0, False), ("rocket", 5, 1, False),
     ]
-    for name, N, seed, gG in cases:
-        d = sweep_case(F, name, N, seed, gG)
-        fn = f"sweep_{name}_N{N}_s{seed}{'_genG' if gG else ''}.npz"
+    cases = [c + (None,) for c in cases] + [("pendulum", 6, 4, False, 2), ("quadrotor", 8, 3, False, 5)]
+    for name, N, seed, gG, nwc in cases:
+        d = sweep_case(F, name, N, seed, gG, nwc)
+        fn = f"sweep_{name}_N{N}_s{seed}{'_genG' if gG else ''}{'_nw%d' % nwc if nwc else ''}.npz"
         np.savez_compressed(os.path.join(OUT, fn), **d)
         print("wrote", fn, {k: getattr(v, 'shape', v) for k, v in d.items() if k in ('K', 'beta', 'backoff')})
     for name in ("pendulum", "quadrotor", "rocket"):

@@ -23,7 +23,7 @@ def relerr(a, b):
 
 
 SWEEP_CASES = ["sweep_pendulum_N10_s0.npz", "sweep_pendulum_N3_s2.npz", "sweep_quadrotor_N20_s0.npz", "sweep_rocket_N20_s0.npz",
-               "sweep_rocket_N5_s1.npz", "sweep_pendulum_N10_s1_genG.npz"]
+               "sweep_rocket_N5_s1.npz", "sweep_pendulum_N10_s1_genG.npz", "sweep_pendulum_N6_s4_nw2.npz", "sweep_quadrotor_N8_s3_nw5.npz"]
 
 
 @pytest.mark.parametrize("case", SWEEP_CASES)
@@ -41,6 +41,14 @@ def test_sweep_vs_reference_golden(case):
         base = m
         m = SimpleNamespace(nx=base.nx, nu=base.nu, nw=base.nw, ni=int(g["ni"]), ni_f=int(g["ni_f"]), G=g["G"], Gf=g["Gf"], gf=np.zeros(int(g["ni_f"])),
                             E=base.E, Q=base.Q, R=base.R, Qf=base.Qf)
+    if "_nw" in case:
+        # fewer disturbance channels than states (nw < nx; dyn/LTV.py:17-32 takes any nw, fast_SLS_jit.py:104-108): dense nx x nw blocks E_j that
+        # differ per stage, golden vectors from the reference's own kernels
+        from types import SimpleNamespace
+        base = m
+        m = SimpleNamespace(nx=base.nx, nu=base.nu, nw=int(g["nw"]), ni=base.ni, ni_f=base.ni_f, G=base.G, Gf=base.Gf, gf=base.gf, E=g["E"][0], Q=base.Q, R=base.R,
+                            Qf=base.Qf)
+        assert m.nw < m.nx and g["E"].shape == (N + 1, m.nx, m.nw)
     f = BatchedFastSLS(N, m.Q, m.R, m, m.Qf, g["Q_reg"], g["R_reg"], g["Q_reg_f"], batch=B)
     rng = np.random.default_rng(5)
     # instance 0 = the golden case; the others are perturbed copies (must not disturb instance 0)
@@ -119,9 +127,10 @@ def test_qp_vs_oracle(model, amps):
             assert np.allclose(y[b][: -m.nx][act], yo[: -m.nx][act], rtol=1e-5, atol=1e-6 * scale)
 
 
-@pytest.mark.parametrize("model,N", [("pendulum", 1), ("pendulum", 32), ("quadrotor", 7), ("rocket", 15)])
+@pytest.mark.parametrize("model,N", [("pendulum", 1), ("pendulum", 32), ("pendulum", 64), ("quadrotor", 7), ("rocket", 15), ("rocket", 40)])
 def test_other_horizons_vs_oracle(model, N):
-    """Horizon edge cases: N = 1 (a single stage), the ABI's maximum N = 32, an odd horizon, and N = 15, the rocket script's own default
+    """Horizon edge cases: N = 1 (a single stage), N = 32 and the ABI's maximum N = 64, an odd horizon, a rocket horizon twice the headline's (the
+    script takes any --N, main_rocket...:458-461), and N = 15, the rocket script's own default
     (expe/main_rocket_robust_closed_loop.py:63).  One RTI fast-SLS step (2 QPs + sweep) against the oracle."""
     insts = [make_instance(model, s, 0.5, N=N) for s in range(2)]
     out = run_gpu_fastsls(insts, rti_steps=1)

@@ -132,11 +132,11 @@ def test_other_horizons_vs_oracle(model, N):
     """Horizon edge cases: N = 1 (a single stage), N = 32 and the ABI's maximum N = 64, an odd horizon, a rocket horizon twice the headline's (the
     script takes any --N, main_rocket...:458-461), and N = 15, the rocket script's own default
     (expe/main_rocket_robust_closed_loop.py:63).  One RTI fast-SLS step (2 QPs + sweep) against the oracle."""
-    insts = [make_instance(model, s, 0.5, N=N) for s in range(2)]
+    insts = [make_instance(model, s, 0.1 if N > 32 else 0.5, N=N) for s in range(2)]      # (the open-loop unstable pendulum over 64 stages: a smaller x0)
     out = run_gpu_fastsls(insts, rti_steps=1)
     for b, inst in enumerate(insts):
         ref = run_oracle_fastsls(inst, rti_steps=1)
-        assert bool(out["success"][b]) == bool(ref["success"])
+        assert bool(out["success"][b]) == bool(ref["success"]) and ref["success"]
         assert out["primal_vec"].shape[1] == inst.m.nz * N + inst.m.nx
         assert relerr(out["primal_vec"][b], ref["primal_vec"]) < 1e-6
         assert relerr(out["backoff"][b], ref["backoff"]) < 1e-6

@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--x0-scale", type=float, default=None, help="closed loop: initial state = hover + s (script x0 - hover); default 1.0 = the script's own state "
                     "(the nominal initialiser then runs its two-stage continuation)")
+    ap.add_argument("--decoupled", type=int, default=1, help="1 (default): the timed closed loop runs through slsqp_cl_run -- every instance advances through its MPC steps "
+                    "independently, a chain of QP solves still running --round-budget-ms after its launch started suspends itself and resumes in the next round (rocket "
+                    "script setting only); 0: one slsqp_cl_step per step for the whole slice")
+    ap.add_argument("--round-budget-ms", type=float, default=5.0)
     ap.add_argument("--secondary-synthetic", action="store_true", help="also time round 1's synthetic step as a secondary figure")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the all-core leg of cpu_baseline")
     args = ap.parse_args()
@@ -159,6 +163,36 @@ class ClosedLoopSlices:
         if err:
             raise err[0]
 
+    def run_decoupled(self, steps, budget_ms):
+        """The whole closed loop of every slice through slsqp_cl_run (instances advance independently, see include/slsqp.h): one call per slice.  Only
+        from closed-loop step 0.  Per-step statistics come from the device-side copy of qp_stats."""
+        import ctypes as C
+        import numpy as np
+        from robust_nonlinear_mpc_amd import _lib as L
+        assert self.step_no == 0
+        acc = [dict(jac=0.0, qp=0.0, sweep=0.0, total=0.0) for _ in self.cl]
+        self.rounds = [0] * len(self.cl)
+
+        def work(k):
+            cl, W = self.cl[k], self.W[k]
+            f = cl.f
+            rounds = C.c_int(0)
+            L.check(f.lib.slsqp_cl_run(f.h, steps, C.c_void_p(W.data_ptr()), L.DEVICE, C.byref(f.opts), float(budget_ms), C.byref(rounds)))
+            self.rounds[k] = rounds.value
+            t = f.timing_ms()
+            for key in acc[k]:
+                acc[k][key] += t[key]
+            self.step_ms[k] = [t["total"] / steps] * steps
+        self._threads(work)
+        self.step_no += steps
+        return acc
+
+    def fetch_run_stats(self, steps):
+        import numpy as np
+        for k, cl in enumerate(self.cl):
+            qs = cl.f.get("log_qp_stats", (steps, 2, 8), np.int32)
+            self.stats[k] = [np.ascontiguousarray(qs[:, s]) for s in range(steps)]
+
     def run(self, steps, collect_stats=True):
         """`steps` closed-loop MPC steps of every slice, each slice on its own thread / stream without waiting for the others.
         Returns per-slice sums of the GPU times (ms) of the linearisations, QP solves and sweeps."""
@@ -255,7 +289,7 @@ def qp_statistics(stats):
 def bench_command(args, n_slices, x0_scale):
     """What a PMC pass must have been taken on to describe this run (profiles/<round>/pmc_traffic*.json hold the same dict under "command")."""
     return {"model": args.model, "batch": args.batch, "steps": args.steps, "warmup": args.warmup, "slices": n_slices, "x0_scale": x0_scale,
-            "precision": args.precision, "workload": args.workload}
+            "precision": args.precision, "workload": args.workload, "decoupled": int(bool(args.decoupled)), "round_budget_ms": args.round_budget_ms}
 
 
 def read_traffic(fname, key, command):
@@ -434,11 +468,14 @@ def main():
         nlp = dev.setup(x0, cont)
         barrier()
         dev.kernel_timing()
+        decoupled = bool(args.decoupled) and args.precision == 0 and m.rti == 1 and m.fast_sls_rti_steps == 1 and int(os.environ.get("QP_FUSE_RTI", "1")) != 0
         t0 = time.perf_counter()
-        acc = dev.run(args.steps)
+        acc = dev.run_decoupled(args.steps, args.round_budget_ms) if decoupled else dev.run(args.steps)
         gather(torch.cat([dev.fetch_device("x_meas", (m.nx,)), dev.fetch_device("u0", (m.nu,))], dim=1))
         barrier()
         dt = time.perf_counter() - t0
+        if decoupled:
+            dev.fetch_run_stats(args.steps)
         x0_txt = "the script's own initial state (expe/main_rocket_robust_closed_loop.py:110-126)" if (x0_scale == 1.0 and args.model == "rocket") else \
             f"hover + {x0_scale} (script x0 - hover)"
         workload = (f"{args.model} N={N} batch={B}/GPU closed-loop Monte-Carlo from script x0" if (x0_scale == 1.0 and "x0" in m.extra) else
@@ -446,12 +483,16 @@ def main():
         workload += (f": one slsqp_cl_step per step (shift + reset, linearise, fast-SLS RTI: {m.rti * (m.fast_sls_rti_steps + 1)} QP solves + "
                      f"{m.rti * m.fast_sls_rti_steps} SLS sweep(s) per instance, nominal update, plant + seeded noise); x0 = {x0_txt}, nominal from the GPU "
                      f"initialiser (untimed); timed steps = closed-loop steps 0..{args.steps - 1}; warm-up = {args.warmup} step(s) of a disjoint seed batch")
+        if decoupled:
+            workload += (f"; the steps run through slsqp_cl_run: every instance advances independently, chains still running {args.round_budget_ms} ms after their launch "
+                         f"started resume in the next round")
         per_step = [np.concatenate([dev.stats[k][s] for k in range(len(dev.cl))]) for s in range(args.steps)]
         qstat = qp_statistics(per_step)
         succ = dev.get("scp_success", (), np.int32)
         step_ms = np.mean(np.array(dev.step_ms), axis=0)          # per closed-loop step: GPU ms of slsqp_cl_step, mean over the rank's slices (they run concurrently)
         extra_cfg = {"nominal_initialiser_converged_frac": float((nlp == 0).mean()), "mpc_step_success_frac_last_step": float(succ.mean()), "qp": qstat,
                      "linearise_ms_per_step": float(np.mean([a["jac"] for a in acc])) / args.steps,
+                     "rounds_per_slice": getattr(dev, "rounds", None), "round_budget_ms": args.round_budget_ms if decoupled else None,
                      "per_step": {"slice_gpu_ms": [round(float(v), 3) for v in step_ms],
                                   "qp_solves_run": [int(((st[:, :, 6] != -1) & (st[:, :, 6] != 2)).sum()) for st in per_step],
                                   "note": "slice_gpu_ms: HIP-event time of one slice's slsqp_cl_step, mean over the slices of rank 0; slices overlap, so the sum "
@@ -507,7 +548,7 @@ def main():
         # HBM traffic from PMC counters: attached only when the committed passes were taken on exactly this command
         command = bench_command(args, n_sl, x0_scale)
         traffic, tsrc = read_traffic("pmc_traffic.json", dom_kernel + "_bytes_per_launch", command)
-        calls = args.steps * n_sl
+        calls = (sum(dev.rounds) if getattr(dev, "rounds", None) else args.steps * n_sl)
         step_tf = (fact_stages * kf + 2.0 * inst_sweeps * N * ks + args.steps * B * sweep_flop) / dt / 1e12
         out["roofline"] = dict({"bound": "mfma", "kernel": dom_kernel, "peak": 78.6, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": tsrc}, **rb)
         out["roofline"].update({

@@ -155,6 +155,13 @@ int slsqp_linearize(slsqp_handle *h, const double *X, const double *U, int loc);
    scp_delta_max (1) primal_infeasibility (1; max_k,i (ddyn(x_k,u_k) - x_{k+1})_i of the updated nominal, SCP_SLS_jit.py:449-456) + all names of the fast-SLS result (for each instance: of its last fast-SLS solve). */
 int slsqp_cl_init(slsqp_handle *h, const double *x_meas, const double *X_nom, const double *U_nom, const double *u_init, int loc);
 int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc, const slsqp_opts *opts);
+/* The whole closed loop with the instances advancing INDEPENDENTLY (rti = 1, one fast-SLS step, fp64, fuse_rti: the rocket script's setting):
+   `steps` MPC steps of every instance, W (steps,B,nx) disturbance samples or NULL.  Per instance the same operations in the same order as `steps`
+   calls of slsqp_cl_step (identical results), but in rounds: in a round an instance begins its next MPC step or resumes the QP solve that the
+   previous round's deadline suspended; a chain still running budget_ms after its launch started suspends itself and continues in the next round.
+   No instance waits for the slowest one of its step.  Call after slsqp_cl_init (+ slsqp_nominal_solve); per-step results through the device-side
+   log (slsqp_cl_log with max_steps >= steps, before slsqp_cl_init) and `log_qp_stats`[int32] (steps,2,8).  *rounds_out (may be NULL): rounds taken. */
+int slsqp_cl_run(slsqp_handle *h, int steps, const double *W, int loc, const slsqp_opts *opts, double budget_ms, int *rounds_out);
 /* Device-side log of the closed loop: every following slsqp_cl_step stores what the scripts keep per MPC step
    (expe/main_rocket_robust_closed_loop.py:160-178) in entry `step` of (B, max_steps, ...) device buffers, so a Monte-Carlo run makes no
    host round trip per step.  slsqp_get names (per instance): log_state (S,nx) log_u0 (S,nu) log_nominal_x (S,N+1,nx) log_nominal_u (S,N,nu)

@@ -23,7 +23,7 @@ EXPORTS = [
     "slsqp_default_opts", "slsqp_last_error", "slsqp_version", "slsqp_create", "slsqp_destroy", "slsqp_set_costs",
     "slsqp_set_constraints", "slsqp_update_dynamics", "slsqp_update_linear_cost", "slsqp_solve", "slsqp_get", "slsqp_reset",
     "slsqp_sync", "slsqp_qp_nnz", "slsqp_qp_update_data_mat", "slsqp_qp_update_data_vec", "slsqp_qp_solve", "slsqp_sweep",
-    "slsqp_last_timing", "slsqp_kernel_timing", "slsqp_stream", "slsqp_set_model", "slsqp_set_E", "slsqp_linearize", "slsqp_cl_init", "slsqp_cl_step", "slsqp_nominal_solve", "slsqp_set", "slsqp_cl_log", "slsqp_selftest", "slsqp_result_bytes",
+    "slsqp_last_timing", "slsqp_kernel_timing", "slsqp_stream", "slsqp_set_model", "slsqp_set_E", "slsqp_linearize", "slsqp_cl_init", "slsqp_cl_step", "slsqp_nominal_solve", "slsqp_set", "slsqp_cl_log", "slsqp_selftest", "slsqp_result_bytes", "slsqp_cl_run",
 ]
 
 _lib = None
@@ -77,6 +77,7 @@ def load():
     lib.slsqp_cl_step.argtypes = [vp, C.c_int, dp, C.c_int, C.POINTER(Opts)]
     lib.slsqp_nominal_solve.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.POINTER(Opts)]
     lib.slsqp_cl_log.argtypes = [vp, C.c_int]
+    lib.slsqp_cl_run.argtypes = [vp, C.c_int, dp, C.c_int, C.POINTER(Opts), C.c_double, C.POINTER(C.c_int)]
     lib.slsqp_selftest.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int]
     lib.slsqp_stream.argtypes = [vp]
     lib.slsqp_stream.restype = vp

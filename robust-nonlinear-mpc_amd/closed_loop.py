@@ -93,6 +93,11 @@ class ClosedLoopMPC:
             self.step(None if W is None else W[i], fetch=False)
             t = f.timing_ms()
             t_qp[i], t_ric[i], t_jac[i] = t["qp"], t["sweep"], t["jac"]
+        return self._log_result(steps, t_jac, t_qp, t_ric)
+
+    def _log_result(self, steps, t_jac, t_qp, t_ric):
+        """The arrays of the device-side log (slsqp_cl_log) laid out like the reference's npz, batch axis first."""
+        f, m, N = self.f, self.m, self.N
         lx = f.get("log_nominal_x", (steps, N + 1, m.nx)); lu = f.get("log_nominal_u", (steps, N, m.nu))
         lbx = f.get("log_backoff_x", (steps, N + 1, m.nx)); lbu = f.get("log_backoff_u", (steps, N, m.nu))
         u0 = f.get("log_u0", (steps, m.nu))
@@ -105,6 +110,28 @@ class ClosedLoopMPC:
             success=f.get("log_success", (steps,), np.int32).astype(bool), scp_iterations=f.get("log_scp_iterations", (steps,), np.int32),
             primal_infeasibility=f.get("log_primal_infeasibility", (steps,)),
         )
+
+    def run_decoupled(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False, continuation=1, budget_ms=6.0):
+        """Same results as run_on_device() -- bit for bit -- through slsqp_cl_run: the instances advance through their MPC steps independently (a
+        chain of QP solves that is not done budget_ms after its launch started suspends itself and resumes in the next round), so nobody waits for the
+        slowest instance of a step.  Only for the rocket script's setting (rti = 1, one fast-SLS step, fp64).  Adds `qp_stats` (B, steps, 2, 8) and
+        `rounds`; the t_* arrays hold the run's totals in their first entry."""
+        f, m, N, B = self.f, self.m, self.N, self.B
+        assert self.rti == 1, "slsqp_cl_run runs rti = 1 closed loops"
+        L.check(f.lib.slsqp_cl_log(f.h, int(steps)))
+        self.reset(x0, X_nom, U_nom, solve_nominal=solve_nominal, continuation=continuation)
+        Wc = None if W is None else _c(W)
+        assert Wc is None or Wc.shape == (steps, B, m.nx)
+        rounds = C.c_int(0)
+        L.check(f.lib.slsqp_cl_run(f.h, int(steps), _ptr(Wc), L.HOST, C.byref(f.opts), float(budget_ms), C.byref(rounds)))
+        self.steps_done = steps
+        t = f.timing_ms()
+        t_qp, t_ric, t_jac = np.zeros((steps, 1)), np.zeros((steps, 1)), np.zeros((steps, 1))
+        t_qp[0], t_ric[0], t_jac[0] = t["qp"], t["sweep"], t["jac"]
+        out = self._log_result(steps, t_jac, t_qp, t_ric)
+        out["qp_stats"] = f.get("log_qp_stats", (steps, 2, 8), np.int32)
+        out["rounds"] = rounds.value
+        return out
 
     def run(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False):
         """Closed loop of `steps` MPC steps from x0 (B,nx); W (steps,B,nx) disturbance samples or None.  Returns arrays laid out

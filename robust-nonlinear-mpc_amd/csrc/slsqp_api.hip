@@ -52,6 +52,11 @@ struct slsqp_handle {
     int horizon_shifted = 0;
     // timeline: event pairs recorded on the stream with a role (0 QP, 1 sweep, 2 whole solve, 3 linearisation, 4 fused RTI chain); read after a synchronisation
     std::vector<hipEvent_t> tl; std::vector<int> tl_role; int tl_n = 0; double tl_acc[5] = {0, 0, 0, 0, 0};     // role 4: fused RTI chain launches (k_rti_chain)
+    // slsqp_cl_run: per-instance progress through the closed loop (step counter, suspended-solve state, round masks), per-instance call ids, the launch's
+    // start-time word, the per-step copy of qp_stats
+    int *cl_stepno = nullptr, *cl_lag = nullptr, *cl_begin = nullptr, *cl_runm = nullptr, *cl_done = nullptr, *cl_skipb = nullptr, *cl_skip_begin = nullptr, *qplog = nullptr;
+    double *call_ids = nullptr, *cl_W = nullptr; size_t cl_W_doubles = 0; unsigned long long *t0word = nullptr; int qplog_steps = 0;
+    bool cl_round = false; unsigned long long cl_budget = 0; int cl_total_steps = 0;
     unsigned long long *chain_times = nullptr, *chain_times_host = nullptr;   // (B,4) in-kernel wall-clock ticks per instance; pinned copy of instance 0's
     int *qp_diag = nullptr;     // QP_DIAG_SPAN builds only
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
@@ -162,7 +167,9 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(h->owned, &h->retry, B); h->mx_retry = 0; h->mx_retry_total = 0;
     rc |= dalloc(h->owned, &h->nom_st, B * 12); rc |= dalloc(h->owned, &h->nom_need_lin, B); rc |= dalloc(h->owned, &h->nom_status, B); rc |= dalloc(h->owned, &h->nom_iters, B);
     rc |= dalloc(h->owned, &h->mapA, (size_t)N * nx * nx); rc |= dalloc(h->owned, &h->mapB, (size_t)N * nx * nu);
-    rc |= dalloc(h->owned, &h->inst_launches, (size_t)8); rc |= dalloc(h->owned, &h->chain_times, B * 4); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
+    rc |= dalloc(h->owned, &h->inst_launches, (size_t)8); rc |= dalloc(h->owned, &h->chain_times, B * 4);
+    rc |= dalloc(h->owned, &h->cl_stepno, B); rc |= dalloc(h->owned, &h->cl_lag, B); rc |= dalloc(h->owned, &h->cl_begin, B); rc |= dalloc(h->owned, &h->cl_runm, B); rc |= dalloc(h->owned, &h->cl_done, B);
+    rc |= dalloc(h->owned, &h->cl_skipb, B); rc |= dalloc(h->owned, &h->call_ids, B); rc |= dalloc(h->owned, &h->t0word, (size_t)2); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
     rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->Kc, B * N * nu * nx); rc |= dalloc(h->owned, &h->Aclc, B * N * nx * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->Gd, (size_t)ni * (nx + nu)); rc |= dalloc(h->owned, &h->Gfd, (size_t)nif * nx); h->general_G = false; h->beta_inited = false; rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
     h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { free_all(h->owned); hipStreamDestroy(h->st); delete h; return nullptr; }
@@ -227,6 +234,8 @@ extern "C" void slsqp_destroy(slsqp_handle *h) {
     free_all(h->log_owned);
     free_all(h->owned);
     if (h->stage) hipFree(h->stage);
+    if (h->cl_W) hipFree(h->cl_W);
+    if (h->qplog) hipFree(h->qplog);
     if (h->chain_times_host) hipHostFree(h->chain_times_host);
     for (auto &e : h->ev) hipEventDestroy(e);
     for (auto &e : h->tl) hipEventDestroy(e);
@@ -458,9 +467,11 @@ struct SolveBeginArgs {
     const int *active; int *alive, *infeas, *success, *pending, *itnum, *stale;
     double *eta, *eta_f; size_t neta, netaf;
     InitBackoffArgs ib;          // run = the instances whose back-offs are reset
+    const int *skip;             // (B) or NULL: instances that are in the middle of a solve (slsqp_cl_run) and must not be touched at all
 };
 __global__ __launch_bounds__(256) void k_solve_begin(SolveBeginArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (a.skip && a.skip[b]) return;
     const int act = a.active ? a.active[b] : 1;
     if (a.x0 && tid < a.NX) a.x0val[(size_t)b * a.NX + tid] = -a.x0[(size_t)b * a.NX + tid];
     if (tid == 0) { a.alive[b] = act; a.infeas[b] = 0; a.success[b] = 0; }
@@ -548,22 +559,39 @@ struct ChainArgs {
     const int *active; int *success; const int *infeas;      // k_finish
     unsigned long long *times;      // (B,4) or NULL: wall_clock64 ticks (100 MHz) of QP #1, the sweep part, QP #2 of each instance
     int max_ticks;
+    // slsqp_cl_run (all NULL / 0 otherwise): instances advance through their MPC steps independently
+    int *lag;                       // (B) 0: the instance starts its chain in this launch; 1 / 2: it was suspended inside QP #1 / QP #2 and resumes there
+    const int *runm;                // (B) 0: the instance takes no part in this launch (it has finished all its steps)
+    int *done;                      // (B) out: 1 = the chain of the instance ended in this launch
+    unsigned long long *t0word;     // start time of the launch (first wave to arrive writes it), zeroed by the host before the launch
+    unsigned long long budget;      // wall-clock ticks (100 MHz) after the start at which unfinished solves suspend themselves
+    int *qplog; const int *stepno; int log_steps;      // (B, log_steps, 16) per-step copy of the instance's qp_stats, entry stepno[b]
 };
 template <int NX, int NU>
 __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_rti_chain(ChainArgs c) {
     int b = blockIdx.x, lane = threadIdx.x;
     if (b >= c.q1.B) return;
+    if (c.runm && !c.runm[b]) return;
     extern __shared__ double sm[];
-    unsigned long long t0 = wall_clock64(), t1 = t0, t2 = t0;
+    unsigned long long t0 = wall_clock64(), t1 = t0, t2 = t0, deadline = ~0ULL;
+    int lg = 0;
+    if (c.lag) {
+        lg = __builtin_amdgcn_readfirstlane(c.lag[b]);
+        unsigned long long first = 0ULL;
+        if (lane == 0) { first = atomicCAS(c.t0word, 0ULL, t0); if (first == 0ULL) first = t0; }
+        first = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(first >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)first);      // (the builtin returns a signed int: no sign extension)
+        deadline = first + c.budget;
+        if (lane == 0) c.done[b] = 0;
+    }
+    int fin = 1;
 #pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-        asm volatile("" : "+s"(b));
+    for (int pass = (lg == 2 ? 1 : 0); pass < 2; pass++) {
         asm volatile("" : "+v"(lane));
-        qp_solve_dev<NX, NU, false>(pass == 0 ? c.q1 : c.q2, b, lane, sm, c.max_ticks);
+        fin = __builtin_amdgcn_readfirstlane(qp_solve_dev<NX, NU, false>(pass == 0 ? c.q1 : c.q2, b, lane, sm, c.max_ticks, (lg == pass + 1) ? 1 : 0, deadline));
         wla::wsync_mem();
+        if (!fin) { if (lane == 0) c.lag[b] = pass + 1; break; }      // suspended at the deadline: the next launch resumes this solve
         if (pass == 1) break;
         t1 = wall_clock64();
-        asm volatile("" : "+s"(b));
         asm volatile("" : "+v"(lane));
         const int m = __builtin_amdgcn_readfirstlane(after_qp_wave(c.aq, b, lane));      // (wave-uniform by construction; said so to the compiler)
         wla::wsync_mem();
@@ -582,11 +610,43 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_rti_chain(Cha
         }
         t2 = wall_clock64();
     }
+    if (!fin) return;
     if (lane == 0) {
         if (c.active && !c.active[b]) c.success[b] = 0;
         else c.success[b] = (!c.infeas[b]) || c.success[b];           // fast_SLS_jit.py:295 (k_finish, RTI)
         if (c.times) { const unsigned long long t3 = wall_clock64(); unsigned long long *t = c.times + (size_t)b * 4; t[0] = t1 - t0; t[1] = t2 - t1; t[2] = t3 - t2; t[3] = t3 - t0; }
+        if (c.lag) { c.lag[b] = 0; c.done[b] = 1; }
     }
+    if (c.qplog && lane < 16) c.qplog[((size_t)b * c.log_steps + min(c.stepno[b], c.log_steps - 1)) * 16 + lane] = c.q1.qpstat[(size_t)b * 16 + lane];
+}
+
+// ---- masked pieces of a closed-loop round (slsqp_cl_run) ----
+// cl_stage[b]: what the instance does in this round -- begin = it starts its next MPC step (shift, reset, linearise, x0 pin, solve start), runm = it runs
+// the chain (begins or resumes), from its step counter and lag state
+__global__ void k_cl_round_masks(int B, int steps, const int *stepno, const int *lag, int *begin, int *runm, int *skip_begin, int *done, int *n_unfinished) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int unfinished = stepno[b] < steps;
+    const int bg = unfinished && lag[b] == 0;
+    begin[b] = bg; runm[b] = unfinished; skip_begin[b] = !bg;
+    done[b] = 0;       // (set by the chain kernel for the instances whose chain ends in this round; instances that take no part must not keep an old 1)
+    if (unfinished) atomicAdd(n_unfinished, 1);
+}
+// reset_solver_to_zeros of slsqp_reset for the instances that begin a step (the others are in the middle of theirs)
+__global__ void k_cl_reset_masked(int B, int n, const int *begin, const int *stepno, int *stale, int *itnum, int *pending, double *q) {
+    const int b = blockIdx.x;
+    if (!begin[b] || stepno[b] == 0) return;
+    for (int o = threadIdx.x; o < n; o += blockDim.x) q[(size_t)b * n + o] = 0.0;
+    if (threadIdx.x == 0) { stale[b] = (stale[b] & 8) | 3; itnum[b] = 0; pending[b] = 0; }
+}
+__global__ void k_cl_advance(int B, const int *done, int *stepno, double *call_ids, const int *begin) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (done[b]) stepno[b] += 1;
+}
+__global__ void k_cl_bump_call(int B, const int *begin, double *call_ids) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && begin[b]) call_ids[b] += 1.0;
 }
 
 __global__ void k_reset_stale(int *p, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = (p[i] & 8) | 3; }   // eta, K: zero on demand; beta keeps its state
@@ -662,7 +722,7 @@ static QpArgs make_qp_args(slsqp_handle *h, const int *run, const slsqp_opts *o,
     QpArgs a;
     a.qpstat = h->qpstat; a.stat_slot = stat_slot; a.diag = h->qp_diag;
     static const double snap_mu = getenv("SLSQP_SNAP_MU") ? atof(getenv("SLSQP_SNAP_MU")) : 1e-3;
-    a.snap_take = snap_take; a.snap_use = snap_use && o->ipm_restart; a.snap_mu = snap_mu; a.call_id = h->call_id; a.as_first = o->as_first; a.as_rounds = o->as_rounds; a.as_max_viol = o->as_max_viol; a.as_warm_max_set = o->as_warm_max_set; a.as_warm_last = o->as_warm_last;
+    a.snap_take = snap_take; a.snap_use = snap_use && o->ipm_restart; a.snap_mu = snap_mu; a.call_id = h->call_id; a.call_ids = h->cl_round ? h->call_ids : nullptr; a.as_first = o->as_first; a.as_rounds = o->as_rounds; a.as_max_viol = o->as_max_viol; a.as_warm_max_set = o->as_warm_max_set; a.as_warm_last = o->as_warm_last;
     { static const double pe = getenv("SLSQP_PINF_EPS") ? atof(getenv("SLSQP_PINF_EPS")) : 1e-4; a.pinf_eps = pe; }
     { static const int ws = getenv("SLSQP_WARM_SHIFT") ? atoi(getenv("SLSQP_WARM_SHIFT")) : 1; a.warm_shift = ws ? warm_shift : 0; }
     a.prox = prox; a.prox_stride = 12; a.inst_launches = h->inst_launches;
@@ -821,7 +881,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     if (h->beta_inited) {     // every solve but the handle's first: the whole preamble in one launch
         SolveBeginArgs sb{B, d.nx, loc == SLSQP_HOST ? nullptr : x0, h->x0val, active, h->alive, h->infeas, h->success, h->pending_reset, h->itnum, h->stale,
                           h->eta, h->eta_f, (size_t)d.N * d.N * d.ni, (size_t)(d.N + 1) * d.ni_f,
-                          InitBackoffArgs{B, d.N, d.nx, d.nu, o.eps_backoff, active, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, 0}};
+                          InitBackoffArgs{B, d.N, d.nx, d.nu, o.eps_backoff, active, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, 0}, h->cl_skip_begin};
         hipLaunchKernelGGL(k_solve_begin, dim3(B), dim3(256), 0, h->st, sb);
     } else {
     if (active) hipLaunchKernelGGL(k_copy_int, dim3(gb), dim3(256), 0, h->st, active, h->alive, B);
@@ -860,6 +920,12 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         c.ta = TightenArgs{B, d.N, d.nx, d.nu, d.ni, d.ni_f, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1, h->ct_part, h->cost_tube};
         c.active = active; c.success = h->success; c.infeas = h->infeas; c.times = h->chain_times;
         c.max_ticks = qp_max_ticks(c.q1, o.qp_max_iter);
+        c.lag = nullptr; c.runm = nullptr; c.done = nullptr; c.t0word = nullptr; c.budget = 0; c.qplog = nullptr; c.stepno = nullptr; c.log_steps = 0;
+        if (h->cl_round) {      // a round of slsqp_cl_run: suspended solves resume, unfinished ones suspend at the deadline
+            c.lag = h->cl_lag; c.runm = h->cl_runm; c.done = h->cl_done; c.t0word = h->t0word; c.budget = h->cl_budget;
+            c.qplog = h->qplog; c.stepno = h->cl_stepno; c.log_steps = h->qplog_steps;
+            HIPCHK(hipMemsetAsync(h->t0word, 0, sizeof(unsigned long long), h->st));
+        }
         const int tl_c = tl_begin(h, 4);
         int rc = -1;
 #define X(NX_, NU_) if (d.nx == NX_ && d.nu == NU_) rc = launch_chain_t<NX_, NU_>(h, c);
@@ -1213,7 +1279,7 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
         tl_end(h, tl_j);
     }
     if (h->log_steps > 0 && h->cl_steps < h->log_steps) {
-        ClLogArgs la{h->B, d.N, d.nx, d.nu, h->log_steps, h->cl_steps, h->Xn, h->Un, h->backoff_x, h->backoff_u, h->scp_success, h->scp_iters,
+        ClLogArgs la{nullptr, nullptr, h->B, d.N, d.nx, d.nu, h->log_steps, h->cl_steps, h->Xn, h->Un, h->backoff_x, h->backoff_u, h->scp_success, h->scp_iters,
                      h->pinf, h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_pinf, h->lg_succ, h->lg_it};
         hipLaunchKernelGGL(k_cl_log, dim3(1024), dim3(256), 0, h->st, la);
     }
@@ -1224,6 +1290,109 @@ extern "C" int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc,
     HIPCHK(hipStreamSynchronize(h->st));
     tl_take(h);
     h->cl_steps++;
+    return 0;
+}
+
+// ---- the whole closed loop with instances advancing independently ------------------------------------------------------------------
+__global__ void k_cl_begin_flags(int B, const int *begin, int *scp_success, int *scp_iters) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && begin[b]) { scp_success[b] = 0; scp_iters[b] = 0; }
+}
+// `steps` MPC steps of every instance (rti = 1 with one fast-SLS step: the rocket script's setting), W (steps, B, nx) or NULL.  Per instance the
+// same sequence of operations as `steps` calls of slsqp_cl_step -- same bits -- but no instance waits for another: the loop runs in ROUNDS (one
+// burst of launches each); in a round an instance either begins its next MPC step (shift, reset, linearise, chain, nominal update, plant) or
+// resumes the QP solve a previous round's deadline suspended; a chain that is not done `budget_ms` after its launch started suspends itself
+// between two block solves and the instance simply takes part in the next round where it stopped.  A batch-wide step lasts as long as its slowest
+// instance (50-90 block solves against a mean of 20: two thirds of a step's time is spent waiting for a few per cent of the instances); a round
+// lasts budget_ms.  Results: the device-side log (slsqp_cl_log with max_steps >= steps), the final state, and log_qp_stats (steps, 2, 8).
+extern "C" int slsqp_cl_run(slsqp_handle *h, int steps, const double *W, int loc, const slsqp_opts *opts, double budget_ms, int *rounds_out) {
+    hipSetDevice(h->dev);
+    if (h->model_id < 0) return fail("slsqp_set_model must be called first");
+    if (h->cl_steps != 0) return fail("slsqp_cl_run starts a closed loop: call slsqp_cl_init first");
+    if (steps < 1) return fail("slsqp_cl_run: steps must be >= 1");
+    if (h->log_steps > 0 && h->log_steps < steps) return fail("slsqp_cl_run: the device-side log (slsqp_cl_log) is shorter than the run");
+    slsqp_opts o;
+    if (opts) o = *opts; else slsqp_default_opts(&o);
+    if (!(o.rti_steps == 1 && o.precision == 0 && o.fuse_rti && chain_allowed() && sweep_shared_allowed()) || h->general_G)
+        return fail("slsqp_cl_run needs the fused RTI chain: rti_steps = 1, fp64, fuse_rti = 1, box constraints (use slsqp_cl_step otherwise)");
+    const slsqp_dims &d = h->d;
+    const int B = h->B, gbi = (B + 255) / 256, gb = (B + 63) / 64;
+    const double *dW = nullptr;
+    if (W) {
+        const size_t nW = (size_t)steps * B * d.nx;
+        if (loc == SLSQP_HOST) {
+            if (nW > h->cl_W_doubles) { if (h->cl_W) hipFree(h->cl_W); h->cl_W = nullptr; h->cl_W_doubles = 0; HIPCHK(hipMalloc((void **)&h->cl_W, nW * sizeof(double) + 64)); h->cl_W_doubles = nW; }
+            HIPCHK(hipMemcpyAsync(h->cl_W, W, nW * sizeof(double), hipMemcpyHostToDevice, h->st));
+            dW = h->cl_W;
+        } else dW = W;
+    }
+    if (h->qplog_steps < steps) {
+        if (h->qplog) hipFree(h->qplog);
+        h->qplog = nullptr; h->qplog_steps = 0;
+        HIPCHK(hipMalloc((void **)&h->qplog, (size_t)B * steps * 16 * sizeof(int) + 64));
+        h->qplog_steps = steps;
+    }
+    HIPCHK(hipMemsetAsync(h->qplog, 0, (size_t)B * h->qplog_steps * 16 * sizeof(int), h->st));
+    h->named["log_qp_stats"] = {h->qplog, sizeof(int) * 16 * (size_t)h->qplog_steps};
+    HIPCHK(hipMemsetAsync(h->cl_stepno, 0, sizeof(int) * B, h->st));
+    HIPCHK(hipMemsetAsync(h->cl_lag, 0, sizeof(int) * B, h->st));
+    hipLaunchKernelGGL(k_fill_doubles, dim3(64), dim3(256), 0, h->st, h->call_ids, h->call_id, (size_t)B);
+    h->cl_budget = (unsigned long long)(std::max(0.05, budget_ms) * 1e5);
+    h->cl_total_steps = steps;
+    ClArgs a = cl_args(h, nullptr);
+    int rounds = 0;
+    const int max_rounds = 40 * steps + 100;
+    for (;; rounds++) {
+        int unfinished = 0;
+        HIPCHK(hipMemsetAsync(h->counter + 1, 0, sizeof(int), h->st));
+        hipLaunchKernelGGL(k_cl_round_masks, dim3(gbi), dim3(256), 0, h->st, B, steps, h->cl_stepno, h->cl_lag, h->cl_begin, h->cl_runm, h->cl_skipb, h->cl_done, h->counter + 1);
+        HIPCHK(hipMemcpyAsync(&unfinished, h->counter + 1, sizeof(int), hipMemcpyDeviceToHost, h->st));
+        HIPCHK(hipStreamSynchronize(h->st));
+        tl_flush(h);
+        if (unfinished == 0) break;
+        if (rounds >= max_rounds) { h->cl_round = false; h->cl_skip_begin = nullptr; return fail("slsqp_cl_run: round limit reached"); }
+        // begin: reset_warm_start (shift + solver reset) for the instances past their first step
+        if (h->model_id == 0) hipLaunchKernelGGL((k_cl_shift_plant<0>), dim3(gb), dim3(64), 0, h->st, a, 1, 0, h->cl_begin, h->cl_stepno, nullptr);
+        else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_shift_plant<1>), dim3(gb), dim3(64), 0, h->st, a, 1, 0, h->cl_begin, h->cl_stepno, nullptr);
+        else hipLaunchKernelGGL((k_cl_shift_plant<2>), dim3(gb), dim3(64), 0, h->st, a, 1, 0, h->cl_begin, h->cl_stepno, nullptr);
+        hipLaunchKernelGGL(k_cl_reset_masked, dim3(B), dim3(256), 0, h->st, B, h->n, h->cl_begin, h->cl_stepno, h->stale, h->itnum, h->pending_reset, h->q);
+        hipLaunchKernelGGL(k_cl_bump_call, dim3(gbi), dim3(256), 0, h->st, B, h->cl_begin, h->call_ids);
+        hipLaunchKernelGGL(k_cl_begin_flags, dim3(gbi), dim3(256), 0, h->st, B, h->cl_begin, h->scp_success, h->scp_iters);
+        h->have_dyn = false;
+        {
+            const int tl_j = tl_begin(h, 3);
+            if (linearize_impl(h, h->Xn, h->Un, SLSQP_DEVICE, h->cl_begin)) return -1;
+            tl_end(h, tl_j);
+        }
+        hipLaunchKernelGGL(k_cl_x0arg, dim3(64), dim3(256), 0, h->st, a, h->cl_begin);
+        h->horizon_shifted = rounds > 0 ? 1 : 0;
+        h->cl_round = true; h->cl_skip_begin = h->cl_skipb;
+        const int rc = solve_impl(h, h->x0arg, SLSQP_DEVICE, &o, h->cl_runm, /* no_sync */ true);
+        h->cl_round = false; h->cl_skip_begin = nullptr;
+        if (rc) return -1;
+        // end of the step for the instances whose chain is done: nominal += delta, primal_infeasibility, log entry, plant + noise, step counter
+        hipLaunchKernelGGL(k_copy_int, dim3(gbi), dim3(256), 0, h->st, h->cl_done, h->scp_active, B);
+        HIPCHK(hipMemsetAsync(h->counter + 2, 0, sizeof(int), h->st));
+        ScpArgs sa{0, 0, o.scp_eps, h->scp_active, h->scp_success, h->scp_iters, h->counter + 2, h->scp_dmax, h->scp_upd};
+        hipLaunchKernelGGL(k_cl_scp_update, dim3(B), dim3(64), 0, h->st, a, sa);
+        if (h->model_id == 0) hipLaunchKernelGGL((k_cl_infeas<0>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
+        else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_infeas<1>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
+        else hipLaunchKernelGGL((k_cl_infeas<2>), dim3(B), dim3(64), 0, h->st, a, h->scp_upd, h->pinf);
+        if (h->log_steps > 0) {
+            ClLogArgs la{h->cl_stepno, h->cl_done, h->B, d.N, d.nx, d.nu, h->log_steps, 0, h->Xn, h->Un, h->backoff_x, h->backoff_u, h->scp_success, h->scp_iters,
+                         h->pinf, h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_pinf, h->lg_succ, h->lg_it};
+            hipLaunchKernelGGL(k_cl_log, dim3(1024), dim3(256), 0, h->st, la);
+        }
+        if (h->model_id == 0) hipLaunchKernelGGL((k_cl_shift_plant<0>), dim3(gb), dim3(64), 0, h->st, a, 0, 1, h->cl_done, h->cl_stepno, dW);
+        else if (h->model_id == 1) hipLaunchKernelGGL((k_cl_shift_plant<1>), dim3(gb), dim3(64), 0, h->st, a, 0, 1, h->cl_done, h->cl_stepno, dW);
+        else hipLaunchKernelGGL((k_cl_shift_plant<2>), dim3(gb), dim3(64), 0, h->st, a, 0, 1, h->cl_done, h->cl_stepno, dW);
+        hipLaunchKernelGGL(k_cl_advance, dim3(gbi), dim3(256), 0, h->st, B, h->cl_done, h->cl_stepno, h->call_ids, h->cl_begin);
+        HIPCHK(hipGetLastError());
+    }
+    tl_take(h);
+    h->cl_steps = steps;
+    h->call_id += steps;
+    if (rounds_out) *rounds_out = rounds;
     return 0;
 }
 

@@ -89,6 +89,7 @@ struct QpArgs {
     int snap_use;             // 1: an instance whose warm active-set attempt fails restarts its interior point from that copy (same A, B, q; other bounds)
     double snap_mu;
     double call_id;           // identifies the fast-SLS call (a copy is only valid within the call that took it: same A, B, q)
+    const double *call_ids;   // (B) or NULL: per-instance call ids instead (slsqp_cl_run: instances of one launch may be in different MPC steps)
     int as_first;             // 1: a cold solve first tries the active-set iteration from the empty set (the equality-constrained optimum of P_INIT)
     int as_rounds;            // rounds such an attempt may take (a warm one: warm_rounds)
     int *diag;                // QP_DIAG_SPAN builds: (B,2,16,2) first / last stage whose set entry changed, per active-set round
@@ -577,6 +578,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
     double *ACT2 = ws + 19 * (size_t)n + 5 * (size_t)N * NX;   // ... and the one its last QP ended on (behind UF; warm start of the next call's last QP, QpArgs::as_warm_last)
     Costs cst = a.cst;
     cst.prox = a.prox ? a.prox[(size_t)b * a.prox_stride] : 0.0;
+    const double call_id = a.call_ids ? a.call_ids[b] : a.call_id;
     QpState *stp = (QpState *)a.state + b;
     // Restart of the interior point from the copy taken by an earlier QP of the same fast-SLS call (same A, B, q; the bounds moved): primal and
     // multipliers are kept, a slack that the new bound would make smaller than min(s, max(sqrt(mu), 1e-3)) is pushed back to that floor.  On the
@@ -628,7 +630,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         const double *prev = a.primal + (size_t)b * n;
         // a later QP of the same call whose previous solve was certified: same A, B, weights, and the scratch still holds the factorisation of
         // exactly the set it starts from -- its first tick needs no factorisation at all
-        const bool keep_fact = warm && !from_act1 && !from_act2 && a.snap_use != 0 && stp->fact_call == a.call_id && a.call_id != 0.0;
+        const bool keep_fact = warm && !from_act1 && !from_act2 && a.snap_use != 0 && stp->fact_call == call_id && call_id != 0.0;
         double set_changed = 0.0;
         double qscale = 0.0, mtot = 0.0;
 #pragma unroll 4
@@ -1077,7 +1079,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         // from its cold start otherwise
         const bool try_cold_as = a.as_first == 1 && s.cold_as == 0.0 && s.warm == 1.0;   // (as_first 2: a failed warm attempt goes straight to the interior point)
         s.pol_round = 0.0; s.pol_fail = 0.0; s.seth[0] = s.seth[1] = s.seth[2] = s.seth[3] = 0ULL; s.uf_valid = 0.0;
-        if (!try_cold_as && a.snap_use && s.snap_call == a.call_id && a.call_id != 0.0) {
+        if (!try_cold_as && a.snap_use && s.snap_call == call_id && call_id != 0.0) {
             s.warm = -1.0; s.path = 10.0 * floor(s.path / 10.0) + 2.0;
             restore_iterate(s.snap_mu);
             s.snap_used = 1.0;
@@ -1150,7 +1152,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
 #pragma unroll 4
             for (int e = lane; e < n; e += 64) { SZ[e] = Z[e]; SSU[e] = SU[e]; SSL[e] = SL[e]; SLU[e] = LU[e]; SLL[e] = LL[e]; SGC[e] = GC[e]; }
             for (int o = lane; o < N * NX; o += 64) SNUA[o] = NUA[o];
-            s.pad2 = 1.0; s.snap_call = a.call_id; s.snap_mu = mu;
+            s.pad2 = 1.0; s.snap_call = call_id; s.snap_mu = mu;
         }
         // An interior point that no longer makes progress is at an infeasible (or hopelessly ill-posed) QP: once the usual iteration count (7-13) is
         // well behind it (24 iterations), max(residual, mu) must at least halve over six iterations, else the solve is flagged like one that ran out of iterations
@@ -1223,7 +1225,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
                 s.act1_ok = (double)((int)s.act1_ok | 2);
             }
         }
-        if (polished) s.fact_call = a.call_id;
+        if (polished) s.fact_call = call_id;
         csum = wla::wave_sum(csum);
         nact = wla::wave_sum(nact);
         if (lane == 0) {
@@ -1251,13 +1253,19 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
 #endif
 
 template <int NX, int NU, bool MX = false>     // MX: the mixed-precision sweeps (ne_forward_mx / ne_backward_mx, section 2.4 of DESIGN.md), same loop and phase logic
-__device__ __forceinline__ void qp_solve_dev(const QpArgs &a, int b, int lane, double *sm, int max_ticks) {
-    if (a.run && !a.run[b]) {       // not part of this solve: its statistics slot says so (status -1)
-        if (a.qpstat && lane < 8) a.qpstat[((size_t)b * 2 + a.stat_slot) * 8 + lane] = (lane == 6) ? -1 : 0;
-        return;
+// resume != 0: the solve was suspended by an earlier launch at its deadline (state in HBM: QpState, workspace) and continues where it stopped.
+// deadline: wall-clock tick (100 MHz) after which the solve suspends itself between two block solves (~0: never).  Returns 1 when the solve has
+// ended (or took no part), 0 when it was suspended.
+__device__ __forceinline__ int qp_solve_dev(const QpArgs &a, int b, int lane, double *sm, int max_ticks, int resume = 0, unsigned long long deadline = ~0ULL) {
+    if (!resume) {
+        if (a.run && !a.run[b]) {       // not part of this solve: its statistics slot says so (status -1)
+            if (a.qpstat && lane < 8) a.qpstat[((size_t)b * 2 + a.stat_slot) * 8 + lane] = (lane == 6) ? -1 : 0;
+            return 1;
+        }
+        phase_update<NX, NU>(a, 1, b, lane);
+        wla::wsync_mem();
     }
-    phase_update<NX, NU>(a, 1, b, lane);
-    wla::wsync_mem();
+    int finished = 1;
     unsigned long long n_sweeps = 0, n_factor = 0, n_fstages = 0, n_bwd_skipped = 0;
 #ifdef QP_STAMP
     long long c_fwd = 0, c_bwd = 0, c_ph = 0, c_t0 = __builtin_readcyclecounter(), c_fwdf = 0;
@@ -1275,6 +1283,7 @@ __device__ __forceinline__ void qp_solve_dev(const QpArgs &a, int b, int lane, d
         QpState *st = (QpState *)a.state + b;
         const int phase = (int)st->phase;
         if (phase == P_DONE) break;
+        if (deadline != ~0ULL && wall_clock64() > deadline) { finished = 0; break; }      // (wave-uniform: one scalar clock read)
         const FwdPlan fp = fwd_plan(st, phase, a.N);
         const bool factor = fp.factor;
         double bmax = 0.0;
@@ -1312,7 +1321,9 @@ __device__ __forceinline__ void qp_solve_dev(const QpArgs &a, int b, int lane, d
 #ifdef QP_STAMP
     if (lane == 0) { double *kk = a.kkt + (size_t)b * 8; kk[2] = (double)c_fwdf; kk[3] = (double)(double)n_fstages; kk[4] = (double)c_fwd; kk[5] = (double)c_bwd; kk[6] = (double)c_ph; kk[7] = (double)(__builtin_readcyclecounter() - c_t0); }
 #endif
-    if (lane == 0) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); atomicAdd(a.inst_launches + 2, n_fstages); atomicAdd(a.inst_launches + 3, n_sweeps ? 1ULL : 0ULL); if (n_bwd_skipped) atomicAdd(a.inst_launches + 4, n_bwd_skipped); }
+    // (a solve counts as one that ran when it ENDS with at least one block solve behind it, whatever number of launches it was spread over)
+    if (lane == 0) { atomicAdd(a.inst_launches, n_sweeps); atomicAdd(a.inst_launches + 1, n_factor); atomicAdd(a.inst_launches + 2, n_fstages); atomicAdd(a.inst_launches + 3, (finished && ((QpState *)a.state + b)->ticks > 0.0) ? 1ULL : 0ULL); if (n_bwd_skipped) atomicAdd(a.inst_launches + 4, n_bwd_skipped); }
+    return finished;
 }
 template <int NX, int NU, bool MX = false>
 __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpArgs a, int max_ticks) {
@@ -2212,10 +2223,11 @@ __global__ __launch_bounds__(64) void k_cl_scp_update(ClArgs a, ScpArgs s) {
         } else { s.scp_success[b] = 1; atomicAdd(s.n_active, 1); }
     }
 }
-__global__ void k_cl_x0arg(ClArgs a) {
+__global__ void k_cl_x0arg(ClArgs a, const int *mask = nullptr) {
     const int tot = a.B * a.NX;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += gridDim.x * blockDim.x) {
         const int b = t / a.NX, i = t % a.NX;
+        if (mask && !mask[b]) continue;
         a.x0arg[t] = a.Xn[(size_t)b * (a.N + 1) * a.NX + i] - a.xmeas[t];
     }
 }
@@ -2241,6 +2253,7 @@ __global__ __launch_bounds__(64) void k_cl_infeas(ClArgs a, const int *updated, 
 // device-side log of a closed-loop run (what the scripts store per MPC step, expe/main_rocket_robust_closed_loop.py:160-178): entry `step`
 // of (B, S, ...) buffers, so a whole Monte-Carlo run needs no host round trip per step
 struct ClLogArgs {
+    const int *stepno, *mask;      // slsqp_cl_run: entry stepno[b] instead of `step`, only for the instances with mask[b] (NULL: all, entry `step`)
     int B, N, NX, NU, S, step;
     const double *Xn, *Un, *bx, *bu;
     const int *success, *scp_iters;
@@ -2254,7 +2267,8 @@ __global__ void k_cl_log(ClLogArgs a) {
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
         const int b = t / per;
         int o = t % per;
-        const size_t e = (size_t)b * a.S + a.step;
+        if (a.mask && !a.mask[b]) continue;
+        const size_t e = (size_t)b * a.S + (a.stepno ? min(a.stepno[b], a.S - 1) : a.step);
         if (o < nX) {
             const double v = a.Xn[(size_t)b * nX + o];
             a.lx[e * nX + o] = v;
@@ -2270,11 +2284,16 @@ __global__ void k_cl_log(ClLogArgs a) {
 }
 // warm-start shift (SCP_SLS_jit.py:508-518): x_k <- x_{k+1}, u_k <- u_{k+1}, u_{N-1} kept, x_N <- ddyn(x_N, u_{N-1});
 // plant step (expe/main_rocket...:180-182): x_meas <- ddyn(x_meas, u0) + E w.   One thread per instance.
+// slsqp_cl_run: mask (B) selects the instances; shift only those past their first step (stepno > 0); the disturbance sample of an instance is the one
+// of ITS step, W_all (steps, B, NX).
 template <int MODEL>
-__global__ void k_cl_shift_plant(ClArgs a, int do_shift, int do_plant) {
+__global__ void k_cl_shift_plant(ClArgs a, int do_shift, int do_plant, const int *mask = nullptr, const int *stepno = nullptr, const double *W_all = nullptr) {
     constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
+    if (mask && !mask[b]) return;
+    if (do_shift && stepno && stepno[b] == 0) return;
+    if (W_all) a.w = W_all + (size_t)stepno[b] * a.B * NX;      // (mask[b] implies stepno[b] < steps: only instances whose chain ended in this round)
     double *X = a.Xn + (size_t)b * (a.N + 1) * NX, *U = a.Un + (size_t)b * a.N * NU;
     if (do_plant) {
         double xm[NX], u[NU], xp[NX];

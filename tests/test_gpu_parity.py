@@ -804,6 +804,41 @@ def test_fused_rti_chain_is_bitwise_the_separate_launches():
     assert t1["qp"] > 0 and t1["sweep"] > 0 and t0["qp"] > 0 and t0["sweep"] > 0               # both report a QP and a sweep time
 
 
+@pytest.mark.parametrize("budget_ms", [0.3, 3.0, 1e6])
+def test_decoupled_closed_loop_is_bitwise_the_step_by_step_loop(budget_ms):
+    """slsqp_cl_run (instances advance through their MPC steps independently; a chain still running `budget_ms` after its launch started suspends
+    itself between two block solves and resumes in the next round) against the step-by-step loop of slsqp_cl_step: per instance the same operations
+    in the same order, so every logged array and every per-QP statistic is identical bit for bit -- whether nearly every solve is cut several
+    times (0.3 ms), only the slow ones (3 ms) or none (the budget never expires: rounds = steps).  Rocket from the script's x0, 96 seeds x 10 steps."""
+    from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
+    m = get_model("rocket")
+    N, B, steps = 20, 96, 10
+    x0 = np.tile(m.extra["x0"], (B, 1))
+    W = np.stack([disturbance_stream(s, steps, m.nx) for s in range(B)], axis=1)
+    cl = ClosedLoopMPC(m, N, B)
+    L = __import__("robust_nonlinear_mpc_amd")._lib
+    assert L.load().slsqp_cl_log(cl.f.h, steps) == 0
+    cl.reset(x0, solve_nominal=True, continuation=2)
+    ref_stats = []
+    for i in range(steps):
+        cl.step(W[i], fetch=False)
+        ref_stats.append(cl.f.get("qp_stats", (2, 8), np.int32))
+    ref = cl._log_result(steps, np.zeros((steps, 1)), np.zeros((steps, 1)), np.zeros((steps, 1)))
+    ref_final = {k: cl.f.get(k, shp) for k, shp in (("x_meas", (m.nx,)), ("nominal_x", (N + 1, m.nx)), ("nominal_u", (N, m.nu)), ("primal_vec", (cl.f.n,)))}
+    cl.close()
+    cl = ClosedLoopMPC(m, N, B)
+    out = cl.run_decoupled(x0, steps, W, solve_nominal=True, continuation=2, budget_ms=budget_ms)
+    fin = {k: cl.f.get(k, shp) for k, shp in (("x_meas", (m.nx,)), ("nominal_x", (N + 1, m.nx)), ("nominal_u", (N, m.nu)), ("primal_vec", (cl.f.n,)))}
+    cl.close()
+    for k in ("state_trajectory", "input_trajectory", "nominal_trajectory_x", "nominal_trajectory_u", "backoff_trajectory_x", "backoff_trajectory_u", "success",
+              "scp_iterations", "primal_infeasibility"):
+        assert np.array_equal(out[k], ref[k], equal_nan=True), k
+    for k in fin:
+        assert np.array_equal(fin[k], ref_final[k], equal_nan=True), k
+    assert np.array_equal(out["qp_stats"], np.stack(ref_stats, axis=1))
+    assert out["rounds"] == steps if budget_ms > 1e5 else out["rounds"] > steps, out["rounds"]
+
+
 def test_config5_shaped_monte_carlo_1024_seeds_30_steps():
     """BASELINE config 5 at its per-GPU size: 1024 disturbance seeds x 30 closed-loop steps of the rocket (N = 20, script weights, rti = 1, one fast-SLS
     step) from the SCRIPT'S OWN initial state (main_rocket...:110-126; nominal by the GPU initialiser's two-stage continuation).  Properties at full size:

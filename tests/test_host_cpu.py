@@ -270,6 +270,13 @@ class _FakeSlices:
                     self.stats[k].append(st)
         return [dict(jac=0.1 * steps, qp=0.5 * steps, sweep=0.2 * steps, total=1.0 * steps) for _ in self.cl]
 
+    def run_decoupled(self, steps, budget_ms):
+        self.rounds = [steps + 2] * len(self.cl)
+        return self.run(steps)
+
+    def fetch_run_stats(self, steps):
+        pass
+
     def fetch_device(self, name, shape):
         import torch
         return torch.from_numpy(np.tile(self.seeds[:, None].astype(float), (1,) + tuple(shape)))

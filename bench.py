@@ -58,7 +58,8 @@ def parse():
     ap.add_argument("--decoupled", type=int, default=1, help="1 (default): the timed closed loop runs through slsqp_cl_run -- every instance advances through its MPC steps "
                     "independently, a chain of QP solves still running --round-budget-ms after its launch started suspends itself and resumes in the next round (rocket "
                     "script setting only); 0: one slsqp_cl_step per step for the whole slice")
-    ap.add_argument("--round-budget-ms", type=float, default=5.0)
+    ap.add_argument("--round-budget-ms", type=float, default=8.0)
+    ap.add_argument("--round-cut-frac", type=float, default=0.0, help="a round's unfinished chains also suspend once this fraction of its participants are done (0: off)")
     ap.add_argument("--secondary-synthetic", action="store_true", help="also time round 1's synthetic step as a secondary figure")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the all-core leg of cpu_baseline")
     args = ap.parse_args()
@@ -163,7 +164,7 @@ class ClosedLoopSlices:
         if err:
             raise err[0]
 
-    def run_decoupled(self, steps, budget_ms):
+    def run_decoupled(self, steps, budget_ms, cut_frac=0.0):
         """The whole closed loop of every slice through slsqp_cl_run (instances advance independently, see include/slsqp.h): one call per slice.  Only
         from closed-loop step 0.  Per-step statistics come from the device-side copy of qp_stats."""
         import ctypes as C
@@ -177,7 +178,7 @@ class ClosedLoopSlices:
             cl, W = self.cl[k], self.W[k]
             f = cl.f
             rounds = C.c_int(0)
-            L.check(f.lib.slsqp_cl_run(f.h, steps, C.c_void_p(W.data_ptr()), L.DEVICE, C.byref(f.opts), float(budget_ms), C.byref(rounds)))
+            L.check(f.lib.slsqp_cl_run(f.h, steps, C.c_void_p(W.data_ptr()), L.DEVICE, C.byref(f.opts), float(budget_ms), float(cut_frac), C.byref(rounds)))
             self.rounds[k] = rounds.value
             t = f.timing_ms()
             for key in acc[k]:
@@ -289,7 +290,7 @@ def qp_statistics(stats):
 def bench_command(args, n_slices, x0_scale):
     """What a PMC pass must have been taken on to describe this run (profiles/<round>/pmc_traffic*.json hold the same dict under "command")."""
     return {"model": args.model, "batch": args.batch, "steps": args.steps, "warmup": args.warmup, "slices": n_slices, "x0_scale": x0_scale,
-            "precision": args.precision, "workload": args.workload, "decoupled": int(bool(args.decoupled)), "round_budget_ms": args.round_budget_ms}
+            "precision": args.precision, "workload": args.workload, "decoupled": int(bool(args.decoupled)), "round_budget_ms": args.round_budget_ms, "round_cut_frac": args.round_cut_frac}
 
 
 def read_traffic(fname, key, command):
@@ -470,7 +471,7 @@ def main():
         dev.kernel_timing()
         decoupled = bool(args.decoupled) and args.precision == 0 and m.rti == 1 and m.fast_sls_rti_steps == 1 and int(os.environ.get("QP_FUSE_RTI", "1")) != 0
         t0 = time.perf_counter()
-        acc = dev.run_decoupled(args.steps, args.round_budget_ms) if decoupled else dev.run(args.steps)
+        acc = dev.run_decoupled(args.steps, args.round_budget_ms, args.round_cut_frac) if decoupled else dev.run(args.steps)
         gather(torch.cat([dev.fetch_device("x_meas", (m.nx,)), dev.fetch_device("u0", (m.nu,))], dim=1))
         barrier()
         dt = time.perf_counter() - t0

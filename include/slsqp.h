@@ -158,10 +158,11 @@ int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc, const slsq
 /* The whole closed loop with the instances advancing INDEPENDENTLY (rti = 1, one fast-SLS step, fp64, fuse_rti: the rocket script's setting):
    `steps` MPC steps of every instance, W (steps,B,nx) disturbance samples or NULL.  Per instance the same operations in the same order as `steps`
    calls of slsqp_cl_step (identical results), but in rounds: in a round an instance begins its next MPC step or resumes the QP solve that the
-   previous round's deadline suspended; a chain still running budget_ms after its launch started suspends itself and continues in the next round.
+   previous round's deadline suspended; a chain still running budget_ms after its launch started (budget_ms <= 0: no time limit), or still running when
+   cut_frac of the round's participants have finished (0 < cut_frac < 1; else off), suspends itself and continues in the next round.
    No instance waits for the slowest one of its step.  Call after slsqp_cl_init (+ slsqp_nominal_solve); per-step results through the device-side
    log (slsqp_cl_log with max_steps >= steps, before slsqp_cl_init) and `log_qp_stats`[int32] (steps,2,8).  *rounds_out (may be NULL): rounds taken. */
-int slsqp_cl_run(slsqp_handle *h, int steps, const double *W, int loc, const slsqp_opts *opts, double budget_ms, int *rounds_out);
+int slsqp_cl_run(slsqp_handle *h, int steps, const double *W, int loc, const slsqp_opts *opts, double budget_ms, double cut_frac, int *rounds_out);
 /* Device-side log of the closed loop: every following slsqp_cl_step stores what the scripts keep per MPC step
    (expe/main_rocket_robust_closed_loop.py:160-178) in entry `step` of (B, max_steps, ...) device buffers, so a Monte-Carlo run makes no
    host round trip per step.  slsqp_get names (per instance): log_state (S,nx) log_u0 (S,nu) log_nominal_x (S,N+1,nx) log_nominal_u (S,N,nu)

@@ -77,7 +77,7 @@ def load():
     lib.slsqp_cl_step.argtypes = [vp, C.c_int, dp, C.c_int, C.POINTER(Opts)]
     lib.slsqp_nominal_solve.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.POINTER(Opts)]
     lib.slsqp_cl_log.argtypes = [vp, C.c_int]
-    lib.slsqp_cl_run.argtypes = [vp, C.c_int, dp, C.c_int, C.POINTER(Opts), C.c_double, C.POINTER(C.c_int)]
+    lib.slsqp_cl_run.argtypes = [vp, C.c_int, dp, C.c_int, C.POINTER(Opts), C.c_double, C.c_double, C.POINTER(C.c_int)]
     lib.slsqp_selftest.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int]
     lib.slsqp_stream.argtypes = [vp]
     lib.slsqp_stream.restype = vp

@@ -111,7 +111,7 @@ class ClosedLoopMPC:
             primal_infeasibility=f.get("log_primal_infeasibility", (steps,)),
         )
 
-    def run_decoupled(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False, continuation=1, budget_ms=6.0):
+    def run_decoupled(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False, continuation=1, budget_ms=8.0, cut_frac=0.0):
         """Same results as run_on_device() -- bit for bit -- through slsqp_cl_run: the instances advance through their MPC steps independently (a
         chain of QP solves that is not done budget_ms after its launch started suspends itself and resumes in the next round), so nobody waits for the
         slowest instance of a step.  Only for the rocket script's setting (rti = 1, one fast-SLS step, fp64).  Adds `qp_stats` (B, steps, 2, 8) and
@@ -123,7 +123,7 @@ class ClosedLoopMPC:
         Wc = None if W is None else _c(W)
         assert Wc is None or Wc.shape == (steps, B, m.nx)
         rounds = C.c_int(0)
-        L.check(f.lib.slsqp_cl_run(f.h, int(steps), _ptr(Wc), L.HOST, C.byref(f.opts), float(budget_ms), C.byref(rounds)))
+        L.check(f.lib.slsqp_cl_run(f.h, int(steps), _ptr(Wc), L.HOST, C.byref(f.opts), float(budget_ms), float(cut_frac), C.byref(rounds)))
         self.steps_done = steps
         t = f.timing_ms()
         t_qp, t_ric, t_jac = np.zeros((steps, 1)), np.zeros((steps, 1)), np.zeros((steps, 1))

@@ -56,7 +56,7 @@ struct slsqp_handle {
     // start-time word, the per-step copy of qp_stats
     int *cl_stepno = nullptr, *cl_lag = nullptr, *cl_begin = nullptr, *cl_runm = nullptr, *cl_done = nullptr, *cl_skipb = nullptr, *cl_skip_begin = nullptr, *qplog = nullptr;
     double *call_ids = nullptr, *cl_W = nullptr; size_t cl_W_doubles = 0; unsigned long long *t0word = nullptr; int qplog_steps = 0;
-    bool cl_round = false; unsigned long long cl_budget = 0; int cl_total_steps = 0;
+    bool cl_round = false; unsigned long long cl_budget = 0; int cl_total_steps = 0; unsigned cl_cut_count = 0xFFFFFFFFu;
     unsigned long long *chain_times = nullptr, *chain_times_host = nullptr;   // (B,4) in-kernel wall-clock ticks per instance; pinned copy of instance 0's
     int *qp_diag = nullptr;     // QP_DIAG_SPAN builds only
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
@@ -565,6 +565,7 @@ struct ChainArgs {
     int *done;                      // (B) out: 1 = the chain of the instance ended in this launch
     unsigned long long *t0word;     // start time of the launch (first wave to arrive writes it), zeroed by the host before the launch
     unsigned long long budget;      // wall-clock ticks (100 MHz) after the start at which unfinished solves suspend themselves
+    unsigned *fin_count; unsigned cut_count;      // chains of this launch that have ended (device counter, zeroed by the host); solves suspend once it reaches cut_count
     int *qplog; const int *stepno; int log_steps;      // (B, log_steps, 16) per-step copy of the instance's qp_stats, entry stepno[b]
 };
 template <int NX, int NU>
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_rti_chain(Cha
 #pragma unroll 1
     for (int pass = (lg == 2 ? 1 : 0); pass < 2; pass++) {
         asm volatile("" : "+v"(lane));
-        fin = __builtin_amdgcn_readfirstlane(qp_solve_dev<NX, NU, false>(pass == 0 ? c.q1 : c.q2, b, lane, sm, c.max_ticks, (lg == pass + 1) ? 1 : 0, deadline));
+        fin = __builtin_amdgcn_readfirstlane(qp_solve_dev<NX, NU, false>(pass == 0 ? c.q1 : c.q2, b, lane, sm, c.max_ticks, (lg == pass + 1) ? 1 : 0, deadline, c.lag ? c.fin_count : nullptr, c.cut_count));
         wla::wsync_mem();
         if (!fin) { if (lane == 0) c.lag[b] = pass + 1; break; }      // suspended at the deadline: the next launch resumes this solve
         if (pass == 1) break;
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_rti_chain(Cha
         if (c.active && !c.active[b]) c.success[b] = 0;
         else c.success[b] = (!c.infeas[b]) || c.success[b];           // fast_SLS_jit.py:295 (k_finish, RTI)
         if (c.times) { const unsigned long long t3 = wall_clock64(); unsigned long long *t = c.times + (size_t)b * 4; t[0] = t1 - t0; t[1] = t2 - t1; t[2] = t3 - t2; t[3] = t3 - t0; }
-        if (c.lag) { c.lag[b] = 0; c.done[b] = 1; }
+        if (c.lag) { c.lag[b] = 0; c.done[b] = 1; atomicAdd(c.fin_count, 1u); }
     }
     if (c.qplog && lane < 16) c.qplog[((size_t)b * c.log_steps + min(c.stepno[b], c.log_steps - 1)) * 16 + lane] = c.q1.qpstat[(size_t)b * 16 + lane];
 }
@@ -920,11 +921,12 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         c.ta = TightenArgs{B, d.N, d.nx, d.nu, d.ni, d.ni_f, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1, h->ct_part, h->cost_tube};
         c.active = active; c.success = h->success; c.infeas = h->infeas; c.times = h->chain_times;
         c.max_ticks = qp_max_ticks(c.q1, o.qp_max_iter);
-        c.lag = nullptr; c.runm = nullptr; c.done = nullptr; c.t0word = nullptr; c.budget = 0; c.qplog = nullptr; c.stepno = nullptr; c.log_steps = 0;
+        c.lag = nullptr; c.runm = nullptr; c.done = nullptr; c.t0word = nullptr; c.budget = 0; c.qplog = nullptr; c.stepno = nullptr; c.log_steps = 0; c.fin_count = nullptr; c.cut_count = 0xFFFFFFFFu;
         if (h->cl_round) {      // a round of slsqp_cl_run: suspended solves resume, unfinished ones suspend at the deadline
             c.lag = h->cl_lag; c.runm = h->cl_runm; c.done = h->cl_done; c.t0word = h->t0word; c.budget = h->cl_budget;
             c.qplog = h->qplog; c.stepno = h->cl_stepno; c.log_steps = h->qplog_steps;
-            HIPCHK(hipMemsetAsync(h->t0word, 0, sizeof(unsigned long long), h->st));
+            c.fin_count = (unsigned *)(h->t0word + 1); c.cut_count = h->cl_cut_count;
+            HIPCHK(hipMemsetAsync(h->t0word, 0, 2 * sizeof(unsigned long long), h->st));
         }
         const int tl_c = tl_begin(h, 4);
         int rc = -1;
@@ -1304,8 +1306,9 @@ __global__ void k_cl_begin_flags(int B, const int *begin, int *scp_success, int 
 // resumes the QP solve a previous round's deadline suspended; a chain that is not done `budget_ms` after its launch started suspends itself
 // between two block solves and the instance simply takes part in the next round where it stopped.  A batch-wide step lasts as long as its slowest
 // instance (50-90 block solves against a mean of 20: two thirds of a step's time is spent waiting for a few per cent of the instances); a round
-// lasts budget_ms.  Results: the device-side log (slsqp_cl_log with max_steps >= steps), the final state, and log_qp_stats (steps, 2, 8).
-extern "C" int slsqp_cl_run(slsqp_handle *h, int steps, const double *W, int loc, const slsqp_opts *opts, double budget_ms, int *rounds_out) {
+// lasts budget_ms at most, and ends earlier once cut_frac of its participants are done (0 < cut_frac < 1; the stragglers of a round then are cut as soon
+// as the bulk has finished, whatever time that took).  budget_ms <= 0: no time limit.  Results: the device-side log (slsqp_cl_log with max_steps >= steps), the final state, and log_qp_stats (steps, 2, 8).
+extern "C" int slsqp_cl_run(slsqp_handle *h, int steps, const double *W, int loc, const slsqp_opts *opts, double budget_ms, double cut_frac, int *rounds_out) {
     hipSetDevice(h->dev);
     if (h->model_id < 0) return fail("slsqp_set_model must be called first");
     if (h->cl_steps != 0) return fail("slsqp_cl_run starts a closed loop: call slsqp_cl_init first");
@@ -1337,7 +1340,7 @@ extern "C" int slsqp_cl_run(slsqp_handle *h, int steps, const double *W, int loc
     HIPCHK(hipMemsetAsync(h->cl_stepno, 0, sizeof(int) * B, h->st));
     HIPCHK(hipMemsetAsync(h->cl_lag, 0, sizeof(int) * B, h->st));
     hipLaunchKernelGGL(k_fill_doubles, dim3(64), dim3(256), 0, h->st, h->call_ids, h->call_id, (size_t)B);
-    h->cl_budget = (unsigned long long)(std::max(0.05, budget_ms) * 1e5);
+    h->cl_budget = budget_ms > 0.0 ? (unsigned long long)(std::max(0.05, budget_ms) * 1e5) : (1ULL << 62);
     h->cl_total_steps = steps;
     ClArgs a = cl_args(h, nullptr);
     int rounds = 0;
@@ -1350,6 +1353,7 @@ extern "C" int slsqp_cl_run(slsqp_handle *h, int steps, const double *W, int loc
         HIPCHK(hipStreamSynchronize(h->st));
         tl_flush(h);
         if (unfinished == 0) break;
+        h->cl_cut_count = (cut_frac > 0.0 && cut_frac < 1.0) ? (unsigned)std::max(1.0, std::ceil(cut_frac * unfinished)) : 0xFFFFFFFFu;
         if (rounds >= max_rounds) { h->cl_round = false; h->cl_skip_begin = nullptr; return fail("slsqp_cl_run: round limit reached"); }
         // begin: reset_warm_start (shift + solver reset) for the instances past their first step
         if (h->model_id == 0) hipLaunchKernelGGL((k_cl_shift_plant<0>), dim3(gb), dim3(64), 0, h->st, a, 1, 0, h->cl_begin, h->cl_stepno, nullptr);

@@ -1256,7 +1256,10 @@ template <int NX, int NU, bool MX = false>     // MX: the mixed-precision sweeps
 // resume != 0: the solve was suspended by an earlier launch at its deadline (state in HBM: QpState, workspace) and continues where it stopped.
 // deadline: wall-clock tick (100 MHz) after which the solve suspends itself between two block solves (~0: never).  Returns 1 when the solve has
 // ended (or took no part), 0 when it was suspended.
-__device__ __forceinline__ int qp_solve_dev(const QpArgs &a, int b, int lane, double *sm, int max_ticks, int resume = 0, unsigned long long deadline = ~0ULL) {
+// fin_count / cut_count (slsqp_cl_run): the solve also suspends itself once cut_count chains of its launch have ended (the few solves still running
+// then are the ones that would keep the launch alive on their own).
+__device__ __forceinline__ int qp_solve_dev(const QpArgs &a, int b, int lane, double *sm, int max_ticks, int resume = 0, unsigned long long deadline = ~0ULL,
+                                            const unsigned *fin_count = nullptr, unsigned cut_count = 0xFFFFFFFFu) {
     if (!resume) {
         if (a.run && !a.run[b]) {       // not part of this solve: its statistics slot says so (status -1)
             if (a.qpstat && lane < 8) a.qpstat[((size_t)b * 2 + a.stat_slot) * 8 + lane] = (lane == 6) ? -1 : 0;
@@ -1283,7 +1286,11 @@ __device__ __forceinline__ int qp_solve_dev(const QpArgs &a, int b, int lane, do
         QpState *st = (QpState *)a.state + b;
         const int phase = (int)st->phase;
         if (phase == P_DONE) break;
-        if (deadline != ~0ULL && wall_clock64() > deadline) { finished = 0; break; }      // (wave-uniform: one scalar clock read)
+        {   // suspend? (wave-uniform: a scalar clock read, one counter read broadcast from the first lane)
+            int stop = (deadline != ~0ULL && wall_clock64() > deadline) ? 1 : 0;
+            if (fin_count) stop |= (__hip_atomic_load(fin_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cut_count) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(stop)) { finished = 0; break; }
+        }
         const FwdPlan fp = fwd_plan(st, phase, a.N);
         const bool factor = fp.factor;
         double bmax = 0.0;

@@ -804,12 +804,13 @@ def test_fused_rti_chain_is_bitwise_the_separate_launches():
     assert t1["qp"] > 0 and t1["sweep"] > 0 and t0["qp"] > 0 and t0["sweep"] > 0               # both report a QP and a sweep time
 
 
-@pytest.mark.parametrize("budget_ms", [0.3, 3.0, 1e6])
-def test_decoupled_closed_loop_is_bitwise_the_step_by_step_loop(budget_ms):
+@pytest.mark.parametrize("budget_ms,cut_frac", [(0.3, 0.0), (3.0, 0.0), (1e6, 0.0), (0.0, 0.7)])
+def test_decoupled_closed_loop_is_bitwise_the_step_by_step_loop(budget_ms, cut_frac):
     """slsqp_cl_run (instances advance through their MPC steps independently; a chain still running `budget_ms` after its launch started suspends
     itself between two block solves and resumes in the next round) against the step-by-step loop of slsqp_cl_step: per instance the same operations
     in the same order, so every logged array and every per-QP statistic is identical bit for bit -- whether nearly every solve is cut several
-    times (0.3 ms), only the slow ones (3 ms) or none (the budget never expires: rounds = steps).  Rocket from the script's x0, 96 seeds x 10 steps."""
+    times (0.3 ms), only the slow ones (3 ms), none (the budget never expires: rounds = steps), or the last 30 % of every round's chains (no time
+    limit, cut_frac 0.7).  Rocket from the script's x0, 96 seeds x 10 steps."""
     from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
     m = get_model("rocket")
     N, B, steps = 20, 96, 10
@@ -827,7 +828,7 @@ def test_decoupled_closed_loop_is_bitwise_the_step_by_step_loop(budget_ms):
     ref_final = {k: cl.f.get(k, shp) for k, shp in (("x_meas", (m.nx,)), ("nominal_x", (N + 1, m.nx)), ("nominal_u", (N, m.nu)), ("primal_vec", (cl.f.n,)))}
     cl.close()
     cl = ClosedLoopMPC(m, N, B)
-    out = cl.run_decoupled(x0, steps, W, solve_nominal=True, continuation=2, budget_ms=budget_ms)
+    out = cl.run_decoupled(x0, steps, W, solve_nominal=True, continuation=2, budget_ms=budget_ms, cut_frac=cut_frac)
     fin = {k: cl.f.get(k, shp) for k, shp in (("x_meas", (m.nx,)), ("nominal_x", (N + 1, m.nx)), ("nominal_u", (N, m.nu)), ("primal_vec", (cl.f.n,)))}
     cl.close()
     for k in ("state_trajectory", "input_trajectory", "nominal_trajectory_x", "nominal_trajectory_u", "backoff_trajectory_x", "backoff_trajectory_u", "success",

@@ -270,7 +270,7 @@ class _FakeSlices:
                     self.stats[k].append(st)
         return [dict(jac=0.1 * steps, qp=0.5 * steps, sweep=0.2 * steps, total=1.0 * steps) for _ in self.cl]
 
-    def run_decoupled(self, steps, budget_ms):
+    def run_decoupled(self, steps, budget_ms, cut_frac=0.0):
         self.rounds = [steps + 2] * len(self.cl)
         return self.run(steps)
 

@@ -6,6 +6,8 @@ src, dst = sys.argv[1], sys.argv[2]
 build = sys.argv[3] if len(sys.argv) > 3 else "?"
 cmd = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 2 --warmup 1 --no-cpu --no-secondary"
 tail_n = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # the bench's timed region = the last tail_n launches of the dominant kernel
+# (0: read it per pass from the bench line that pass printed -- <src>/../pmc_s<slices>_<COUNTER>.log -- the decoupled loop takes a timing-dependent
+#  number of rounds = launches per slice)
 slices = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 extra = sys.argv[7:]                                         # further bench flags the passes ran with (none for the default command)
 DOM = "k_rti_chain"
@@ -31,12 +33,22 @@ if DOM not in out:
 for kn in ("k_rti_chain", "k_qp_solve", "k_sweep_prop", "k_sweep_ric1", "k_lin_tan"):
     if kn in out:
         res[kn + "_bytes_per_launch"] = out[kn]["fetch_bytes_per_launch_x2"] + out[kn]["write_bytes_per_launch"]
-if tail_n > 0 and DOM in per_disp:
+if DOM in per_disp:
     # same launches as bench.py's roofline averages: the last tail_n dispatches of the dominant kernel (the earlier ones belong to the untimed set-up / warm-up)
     tot = 0.0
     for cn, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         dd = per_disp[DOM].get(cn, {})
-        last = sorted(dd)[-tail_n:]
+        n_tail = tail_n
+        if n_tail <= 0:
+            import os
+            try:
+                line = [l for l in open(os.path.join(os.path.dirname(src.rstrip("/")), f"pmc_s{slices}_{cn}.log")) if l.startswith("{")][-1]
+                cfg = json.loads(line)["config"]
+                n_tail = sum(cfg["rounds_per_slice"]) if cfg.get("rounds_per_slice") else 30 * slices
+            except Exception:
+                n_tail = 30 * slices
+            res.setdefault("timed_region_launches_per_pass", {})[cn] = n_tail
+        last = sorted(dd)[-n_tail:]
         tot += mult * 1024.0 * sum(dd[i] for i in last) / max(1, len(last))
     res[DOM + "_bytes_per_launch_timed_region"] = tot
     res["timed_region_launches"] = tail_n

@@ -2,8 +2,8 @@
 # usage (on the GPU box, from the repo root): scripts/profile_round.sh <tag> [bench flags]
 # rocprofv3 kernel statistics and PMC passes of the DEFAULT bench command (rocket N=20, 4096 seeds from the script's x0, closed-loop steps 0..29, 3 slices)
 # and of its --slices 1 variant, written under gpurun_out/<tag>/.  Counters are collected in their own passes (never combined with a trace domain);
-# the program itself follows `--`.  The timed region of a pass = the LAST steps x slices launches of the dominant kernel (k_rti_chain): the passes run
-# with --no-cpu --no-secondary, so nothing follows the timed region.
+# the program itself follows `--`.  The timed region of a pass = the LAST launches of the dominant kernel (k_rti_chain), as many as the rounds the pass's
+# own bench line reports (config.rounds_per_slice): the passes run with --no-cpu --no-secondary, so nothing follows the timed region.
 tag=${1:-prof}
 shift
 root=$GRAFT_REPO_ROOT
@@ -30,8 +30,8 @@ for sl in 3 1; do
   [ -n "$f" ] && cp $f $out/kernel_stats_s$sl.csv
   # per-dispatch durations of the dominant kernel
   t=$(ls $out/stats_s$sl/*kernel_trace.csv $out/stats_s$sl/*/*kernel_trace.csv 2>/dev/null | head -1)
-  [ -n "$t" ] && python3 - "$t" $out/k_rti_chain_dispatches_s$sl.csv <<'PY'
-import csv, sys
+  [ -n "$t" ] && python3 - "$t" $out/k_rti_chain_dispatches_s$sl.csv $out/stats_s$sl.log $out/kernel_time_s$sl.json $sl <<'PY'
+import csv, json, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_rti_chain" in r["Kernel_Name"] or "k_qp_solve" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 with open(sys.argv[2], "w") as f:
@@ -40,8 +40,18 @@ with open(sys.argv[2], "w") as f:
     for i, r in enumerate(rows):
         nm = "k_rti_chain" if "k_rti_chain" in r["Kernel_Name"] else "k_qp_solve"
         f.write(f"{i},{nm},{int(r['Start_Timestamp']) - t0},{int(r['End_Timestamp']) - int(r['Start_Timestamp'])},{r.get('Grid_Size_X', r.get('Grid_Size', ''))}\n")
+# the timed region of this pass: the last sum(rounds) launches of k_rti_chain, rounds from the bench line the pass printed
+try:
+    line = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1])
+    rounds = line["config"].get("rounds_per_slice") or [line["steps"]] * int(sys.argv[5])
+    chain = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if "k_rti_chain" in r["Kernel_Name"]]
+    n = sum(rounds)
+    json.dump({"rounds_per_slice": rounds, "timed_region_launches": n, "k_rti_chain_mean_ms_timed_region": sum(chain[-n:]) / max(1, len(chain[-n:])) / 1e6,
+               "bench_ms_per_step_under_profiler": line["ms_per_step"], "bench_roofline_avg_launch_ms": line["roofline"]["avg_launch_ms"]}, open(sys.argv[4], "w"), indent=1)
+except Exception as e:
+    print("kernel_time summary failed:", e)
 PY
-  python3 scripts/pmc_traffic.py $out/pmc_s$sl $out/pmc_traffic_s$sl.json "$build" "$cmd --slices $sl" $((steps * sl)) $sl "$@" > /dev/null
+  python3 scripts/pmc_traffic.py $out/pmc_s$sl $out/pmc_traffic_s$sl.json "$build" "$cmd --slices $sl" 0 $sl "$@" > /dev/null
 done
 python3 scripts/pmc_sq.py $out/pmc_sq $out/pmc_sq.json "$cmd --slices 1" > $out/pmc_sq_summary.txt 2>&1
 # keep what is copied back small: the raw per-dispatch csv files stay on the box

@@ -542,6 +542,7 @@ def main():
         # rocket script setting (rti = 1, one fast-SLS step) in fp64: the whole RTI solve of an instance is ONE launch (k_rti_chain: QP -> eta -> Riccati /
         # propagation -> tightened bounds -> QP), the timed launches are those and their work includes the SLS sweeps of the instances whose first QP solved
         fused = (args.workload == "closed_loop" and m.fast_sls_rti_steps == 1 and args.precision == 0 and int(os.environ.get("QP_FUSE_RTI", "1")) != 0
+                 and (decoupled or (B // max(1, n_sl)) * (N + 1) >= 3072)
                  and int(os.environ.get("SLSQP_FUSE_RTI", "1")) != 0)
         sls_sweeps = int(sum(int(np.isin(st_[:, 0, 6], (0, 4)).sum()) for st_ in per_step)) if fused else 0
         dom_kernel = "k_rti_chain" if fused else "k_qp_solve"

@@ -89,9 +89,11 @@ typedef struct {
     int as_warm_last;    /* 1 (default): where as_warm_max_set rules out the first QP's set (or the first QP left no certified set), the last QP of a call starts
                             from the certified active set of the PREVIOUS call's last QP, moved one stage with the horizon after slsqp_cl_step's shift;
                             2: whenever such a set exists; 0: never */
-    int fuse_rti;        /* 1 (default): an RTI solve with rti_steps = 1 in fp64 (the rocket script's setting) runs as ONE launch in which every wavefront takes
-                            its instance through QP -> eta -> Riccati / propagation -> tightened bounds -> QP (k_rti_chain): no batch-wide barrier behind
-                            a QP, so a slow instance only delays itself.  0: the separate launches.  Same arithmetic, same results bit for bit. */
+    int fuse_rti;        /* 1 (default): an RTI solve with rti_steps = 1 in fp64 (the rocket script's setting) of a batch with B (N+1) >= 3072 runs as ONE launch
+                            in which every wavefront takes its instance through QP -> eta -> Riccati / propagation -> tightened bounds -> QP (k_rti_chain): no
+                            batch-wide barrier behind a QP, so a slow instance only delays itself.  Smaller batches keep the separate launches (their SLS
+                            propagation runs N+1 columns of an instance side by side: lower latency).  2: the chain whatever the batch; 0: never.
+                            Same arithmetic, same results bit for bit. */
 } slsqp_opts;
 
 void slsqp_default_opts(slsqp_opts *o);

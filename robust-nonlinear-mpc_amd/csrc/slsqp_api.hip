@@ -905,7 +905,11 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
         h->beta_inited = true;
     }
     }
-    if (rti && steps == 1 && o.precision == 0 && o.fuse_rti && chain_allowed() && sweep_shared_allowed() && !h->general_G) {
+    // (small batches keep the separate launches: there the SLS propagation of an instance runs as N + 1 waves side by side, which is what a B = 1 caller
+    // waits for -- 1.1 against 1.6 ms per rocket RTI step -- while from ~150 instances on the columns of one instance would only compete with other
+    // instances' for the same SIMDs.  fuse_rti = 2 forces the chain, slsqp_cl_run always uses it.)
+    const bool fuse_here = o.fuse_rti == 2 || h->cl_round || (o.fuse_rti == 1 && (long)B * (d.N + 1) >= 3072);
+    if (rti && steps == 1 && o.precision == 0 && fuse_here && chain_allowed() && sweep_shared_allowed() && !h->general_G) {
         // fast_SLS.solve with rti_steps = 1 (the rocket script's setting) as ONE launch: every wave takes its instance through the whole chain
         h->time_kernels = o.time_kernels != 0;
         ChainArgs c;

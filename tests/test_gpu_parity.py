@@ -783,7 +783,7 @@ def test_fused_rti_chain_is_bitwise_the_separate_launches():
     res = []
     for fuse in (1, 0):
         cl = ClosedLoopMPC(m, N, B)
-        cl.f.opts.fuse_rti = fuse
+        cl.f.opts.fuse_rti = 2 * fuse          # 2: the chain although the batch is small; 0: the separate launches
         cl.reset(np.tile(m.extra["x0"], (B, 1)), solve_nominal=True, continuation=2)
         outs = [cl.step(W[i]) for i in range(steps)]
         f = cl.f

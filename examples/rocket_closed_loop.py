@@ -29,12 +29,14 @@ def main():
     ap.add_argument("--init", default="sqp", choices=["sqp", "rollout"])
     ap.add_argument("--continuation", type=int, default=2, help="stages of the initial-state continuation of the nominal NLP (far-away x0)")
     ap.add_argument("--slices", type=int, default=3, help="independent slices (own stream + host thread) the seeds are cut into")
+    ap.add_argument("--round-budget-ms", type=float, default=None, help="run the loop through slsqp_cl_run: instances advance independently, rounds of this length")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     m = get_model("rocket")
     x0 = m.x_ref + a.x0_scale * (m.extra["x0"] - m.x_ref)
     t0 = time.perf_counter()
-    r = run_monte_carlo(m, a.N, np.arange(a.seeds), a.steps, x0, solve_nominal=(a.init == "sqp"), slices=a.slices, continuation=a.continuation)
+    r = run_monte_carlo(m, a.N, np.arange(a.seeds), a.steps, x0, solve_nominal=(a.init == "sqp"), slices=a.slices, continuation=a.continuation,
+                        budget_ms=a.round_budget_ms)
     dt = time.perf_counter() - t0
     ok = r["success"]
     if "nlp_status" in r:

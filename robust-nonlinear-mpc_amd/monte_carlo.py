@@ -15,19 +15,26 @@ def disturbance_stream(seed, steps, nx):
     return np.stack([2.0 * rs.rand(nx) - 1.0 for _ in range(steps)])
 
 
-def _run_slice(model, N, seeds, steps, x0, device, noise, solve_nominal, continuation=1):
+def _run_slice(model, N, seeds, steps, x0, device, noise, solve_nominal, continuation=1, budget_ms=None):
     B = len(seeds)
     W = np.stack([disturbance_stream(s, steps, model.nx) for s in seeds], axis=1) if noise else None   # (steps, B, nx)
     cl = ClosedLoopMPC(model, N, B, device=device)
-    out = cl.run_on_device(np.tile(np.asarray(x0, dtype=float), (B, 1)), steps, W, solve_nominal=solve_nominal, continuation=continuation)
+    X0 = np.tile(np.asarray(x0, dtype=float), (B, 1))
+    if budget_ms is not None and cl.rti == 1 and model.fast_sls_rti_steps == 1:      # instances advance independently (slsqp_cl_run): same bits
+        out = cl.run_decoupled(X0, steps, W, solve_nominal=solve_nominal, continuation=continuation, budget_ms=budget_ms)
+    else:
+        out = cl.run_on_device(X0, steps, W, solve_nominal=solve_nominal, continuation=continuation)
     if cl.nlp_status is not None:
         out.update(nlp_status=cl.nlp_status, nlp_iterations=cl.nlp_iterations)
     cl.close()
     return out
 
 
-def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise=True, gather=True, solve_nominal=False, slices=1, continuation=1):
-    """slices > 1: the rank's seeds are cut into that many independent slices, each with its own handle (HIP stream) and host thread
+def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise=True, gather=True, solve_nominal=False, slices=1, continuation=1,
+                    budget_ms=None):
+    """budget_ms (rocket setting only): run every slice's loop through slsqp_cl_run -- no instance waits for the slowest one of its step; results are
+    the same bit for bit.
+    slices > 1: the rank's seeds are cut into that many independent slices, each with its own handle (HIP stream) and host thread
     (as in fast_sls.SlicedDeviceBatch): results are bit-identical, the slices' solver tails overlap each other's bulk launches."""
     import threading
     seeds = np.asarray(seeds)
@@ -41,7 +48,7 @@ def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise
 
     def work(k):
         try:
-            parts[k] = _run_slice(model, N, mine[cuts[k][0]:cuts[k][1]], steps, x0, device, noise, solve_nominal, continuation)
+            parts[k] = _run_slice(model, N, mine[cuts[k][0]:cuts[k][1]], steps, x0, device, noise, solve_nominal, continuation, budget_ms)
         except Exception as e:
             err.append(e)
 
@@ -57,7 +64,9 @@ def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise
         raise err[0]
     out = {}
     for key, v in parts[0].items():
-        if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == cuts[0][1] - cuts[0][0] and key not in ("t_jac", "t_qp", "t_riccati"):
+        if key == "rounds":
+            out[key] = [p[key] for p in parts]
+        elif isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == cuts[0][1] - cuts[0][0] and key not in ("t_jac", "t_qp", "t_riccati"):
             out[key] = np.concatenate([p[key] for p in parts], axis=0)
         elif key in ("t_qp", "t_riccati", "t_jac"):
             out[key] = np.max(np.stack([p[key] for p in parts]), axis=0)      # slices run concurrently

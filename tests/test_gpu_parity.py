@@ -893,8 +893,10 @@ def test_monte_carlo_seeds_and_npz_keys(tmp_path):
     assert not np.allclose(r1["state_trajectory"][0][:, 1:], r1["state_trajectory"][1][:, 1:])
     assert r1["success"].all()
     r3 = run_monte_carlo(m, 20, [0, 1, 2, 0], 3, x0, slices=3)                        # 3 free-running slices: same bits
+    r4 = run_monte_carlo(m, 20, [0, 1, 2, 0], 3, x0, slices=2, budget_ms=0.3)         # ... and through slsqp_cl_run with a budget that cuts every solve
     for k in ("state_trajectory", "input_trajectory", "nominal_trajectory_x", "backoff_trajectory_x", "success"):
         assert np.array_equal(r1[k], r3[k]), k
+        assert np.array_equal(r1[k], r4[k]), k
     cl = ClosedLoopMPC(m, 20, 1)
     cl.save_npz(str(tmp_path / "run.npz"), {k: v[:1] if isinstance(v, np.ndarray) and v.shape[:1] == (4,) else v for k, v in r1.items()})
     cl.close()

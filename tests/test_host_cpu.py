@@ -183,7 +183,7 @@ def test_disturbance_stream_matches_reference_seed0(golden_dir):
     assert np.array_equal(disturbance_stream(0, 30, 17), W)
 
 
-def _fake_run_slice(model, N, seeds, steps, x0, device, noise, solve_nominal, continuation=1):
+def _fake_run_slice(model, N, seeds, steps, x0, device, noise, solve_nominal, continuation=1, budget_ms=None):
     """Stand-in for the GPU closed loop of one slice: trajectories that encode (seed, step) so the gather can be checked exactly."""
     seeds = np.asarray(seeds)
     S = len(seeds)

@@ -294,16 +294,23 @@ def bench_command(args, n_slices, x0_scale):
 
 
 def read_traffic(fname, key, command):
-    """HBM bytes per launch from the committed PMC passes -- only when they were taken on exactly this command; otherwise null."""
-    p = os.path.join(ROOT, "profiles", PROFILE_DIR, fname)
-    if not os.path.exists(p):
-        return None, f"no PMC pass in profiles/{PROFILE_DIR}/{fname}"
-    d = json.load(open(p))
-    if d.get("command") != command:
-        return None, f"profiles/{PROFILE_DIR}/{fname} is of another command ({d.get('command')}): not attached"
-    if key + "_timed_region" in d:      # per launch of the timed region's launches only (the file also averages the untimed set-up's)
-        key = key + "_timed_region"
-    return d.get(key), f"profiles/{PROFILE_DIR}/{fname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scripts/pmc_traffic.py; build {d.get('build', '?')})"
+    """HBM bytes per launch from the committed PMC passes -- only from a pass that was taken on exactly this command (any profiles/<round>/pmc_traffic*.json
+    whose "command" dictionary equals `command`); otherwise null.  `fname` is looked at first."""
+    import glob
+    d0 = os.path.join(ROOT, "profiles", PROFILE_DIR)
+    files = [os.path.join(d0, fname)] + sorted(f for f in glob.glob(os.path.join(d0, "pmc_traffic*.json")) if os.path.basename(f) != fname)
+    seen = []
+    for p in files:
+        if not os.path.exists(p):
+            continue
+        d = json.load(open(p))
+        if d.get("command") != command:
+            seen.append(os.path.basename(p))
+            continue
+        k = key + "_timed_region" if key + "_timed_region" in d else key      # per launch of the timed region's launches only (the file also averages the untimed set-up's)
+        return d.get(k), (f"profiles/{PROFILE_DIR}/{os.path.basename(p)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scripts/pmc_traffic.py; "
+                          f"build {d.get('build', '?')})")
+    return None, f"no PMC pass of this command in profiles/{PROFILE_DIR} (looked at: {seen})"
 
 
 def reduce_over_ranks(dt, qp_done, world, backend):

@@ -26,8 +26,15 @@ for k, v in acc.items():
     fetch, write = v.get("FETCH_SIZE", 0.0) * 1024 / nf, v.get("WRITE_SIZE", 0.0) * 1024 / nw
     out[k] = {"launches": nf, "fetch_bytes_per_launch_raw": fetch, "fetch_bytes_per_launch_x2": 2 * fetch, "write_bytes_per_launch": write}
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), command: " + cmd, "build": build, "kernels": out}
-if not extra:      # the default bench command: what bench.py's bench_command() must equal for the figure to be attached to a bench line
-    res["command"] = {"model": "rocket", "batch": 4096, "steps": 30, "warmup": 1, "slices": slices, "x0_scale": 1.0, "precision": 0, "workload": "closed_loop", "decoupled": 1, "round_budget_ms": 8.0, "round_cut_frac": 0.0}
+# the command dictionary bench.py's bench_command() must equal for the figure to be attached to a bench line: the default command, with --steps / --warmup
+# taken from the pass's command line
+import re
+def _flag(name, default):
+    m = re.search(r"--" + name + r"\s+(\S+)", cmd)
+    return type(default)(m.group(1)) if m else default
+if not [e for e in extra if e not in ("--steps", "--warmup") and not e.isdigit()]:
+    res["command"] = {"model": "rocket", "batch": 4096, "steps": _flag("steps", 30), "warmup": _flag("warmup", 1), "slices": slices, "x0_scale": 1.0, "precision": 0,
+                      "workload": "closed_loop", "decoupled": 1, "round_budget_ms": 8.0, "round_cut_frac": 0.0}
 if DOM not in out:
     DOM = "k_qp_solve"
 for kn in ("k_rti_chain", "k_qp_solve", "k_sweep_prop", "k_sweep_ric1", "k_lin_tan"):

@@ -10,8 +10,9 @@ root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-steps=30
-cmd="python3 $root/bench.py --steps $steps --warmup 1 --no-cpu --no-secondary $@"
+steps=${STEPS:-30}
+warm=${WARMUP:-1}
+cmd="python3 $root/bench.py --steps $steps --warmup $warm --no-cpu --no-secondary $@"
 for sl in 3 1; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s$sl -o s$sl -- $cmd --slices $sl > $out/stats_s$sl.log 2>&1 || echo "stats pass (slices $sl) failed"
   for c in FETCH_SIZE WRITE_SIZE; do

@@ -609,7 +609,14 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         // resemble each other more than a tightened and an un-tightened one: 2.8 against 3.9 rounds, scripts/proto/as_warm_sources.py) -- also
         // when the solve in between did not end on a certificate (e.g. a measured state outside its own box, status 2): ACT1 is only ever
         // written with a certified set
-        const int okbits = (int)stp->act1_ok;      // bit 0: ACT1 holds a certified set, bit 1: ACT2 does
+        // act1_ok packs: bit 0 ACT1 holds a certified set, bit 1 ACT2 does; bits 2..9 / 10..17 the horizon shifts since ACT1 / ACT2 were written.  A set is
+        // moved by as many stages as the horizon has moved since it was certified -- not by one: a step that is flagged at x0 (or whose solve fails)
+        // writes no set, and the next step's QP would otherwise start from a set that is one stage off (the rocket loop from the script's x0 flags
+        // 5-20 % of the steps; their successors were most of the warm attempts that failed)
+        int okbits = (int)stp->act1_ok;
+        int age1 = (okbits >> 2) & 255, age2 = (okbits >> 10) & 255;
+        if (a.stat_slot == 0 && a.snap_use == 0 && a.warm_shift) { age1 = min(age1 + 1, 255); age2 = min(age2 + 1, 255); }      // the call's first QP sees the shift once
+        okbits = (okbits & 3) | (age1 << 2) | (age2 << 10);
         const bool from_act1 = a.warm && status == ST_INIT && a.stat_slot == 0 && a.snap_use == 0 && (okbits & 1);
         bool warm = a.warm && status == ST_INIT && (from_act1 || (((int)stp->status == 0) && ((int)stp->phase == P_DONE)));
         // The last QP of a call (tightened bounds).  Its natural starting set is the first QP's (same A, B, q, factorisation at hand), and up to
@@ -641,7 +648,9 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             if (warm) {
                 const double ac_old = ACT[e];
                 const double *src = from_act1 ? ACT1 : ACT2;
-                double ac = (from_act1 || from_act2) ? ((a.warm_shift && e + NZ < n) ? src[e + NZ] : src[e]) : ac_old;
+                int es = e + (from_act1 ? age1 : age2) * NZ;      // the same component, as many stages later as the horizon moved; past the end: the last stage that has it
+                while (es >= n) es -= NZ;
+                double ac = (from_act1 || from_act2) ? src[es] : ac_old;
                 if ((ac > 0.0 && !el.fu) || (ac < 0.0 && !el.fl) || !el.fr) ac = 0.0;
                 if (ac != ac_old) set_changed = 1.0;
                 const double zp = (e < NX) ? a.x0val[(size_t)b * NX + e] : prev[e];
@@ -663,7 +672,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             s0.mtot = mtot; s0.pol_round = 0; s0.pol_fail = 0; s0.warm = warm ? 1.0 : 0.0; s0.kst = 0; s0.kbox = 0; s0.ksign = 0; s0.pst = -1; s0.pbox = -1; s0.psign = -1; s0.ticks = 0; s0.fticks = 0; s0.tight = 0; s0.pad = 0;
             s0.snap_call = stp->snap_call; s0.snap_mu = stp->snap_mu; s0.snap_used = 0; s0.pad2 = 0;
             s0.mode = (a.as_first && !big_set) ? 0.0 : 1.0; s0.cold_as = big_set ? 1.0 : 0.0; s0.nviol = 0; s0.path = warm ? (from_act2 ? 20.0 : 10.0) : (big_set ? 1.0 : 0.0);
-            s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = stp->act1_ok; s0.uf_valid = 0; s0.res_only = 0; s0.tbox = 0; s0.stall_ref = 0; s0.stall_it = 0;
+            s0.seth[0] = s0.seth[1] = s0.seth[2] = s0.seth[3] = 0ULL; s0.kmin = skip_fact ? (double)N : 0.0; s0.fact_call = 0; s0.act1_ok = (double)okbits; s0.uf_valid = 0; s0.res_only = 0; s0.tbox = 0; s0.stall_ref = 0; s0.stall_it = 0;
             *stp = s0;
             a.status[b] = status; a.iters[b] = 0;
 #ifdef QP_DIAG_SPAN
@@ -1218,11 +1227,11 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
             for (int o = lane; o < N * NX; o += 64) du[(o / NX) * SR + (o % NX)] = nus[o];
             if (polished && a.stat_slot == 0 && a.snap_use == 0) {     // the call's first QP: its set is where the next call's first QP starts
                 for (int e = lane; e < n; e += 64) ACT1[e] = ACT[e];
-                s.act1_ok = (double)((int)s.act1_ok | 1);
+                s.act1_ok = (double)((((int)s.act1_ok | 1)) & ~(255 << 2));       // written now: age 0
             }
             if (polished && a.stat_slot == 1) {                        // the call's last QP: where the next call's last QP may start (as_warm_last)
                 for (int e = lane; e < n; e += 64) ACT2[e] = ACT[e];
-                s.act1_ok = (double)((int)s.act1_ok | 2);
+                s.act1_ok = (double)((((int)s.act1_ok | 2)) & ~(255 << 10));
             }
         }
         if (polished) s.fact_call = call_id;

@@ -94,6 +94,10 @@ typedef struct {
                             batch-wide barrier behind a QP, so a slow instance only delays itself.  Smaller batches keep the separate launches (their SLS
                             propagation runs N+1 columns of an instance side by side: lower latency).  2: the chain whatever the batch; 0: never.
                             Same arithmetic, same results bit for bit. */
+    int cl_persistent;   /* 1 (default): slsqp_cl_run is ONE persistent launch (k_cl_loop): wavefronts take instances from a device-side FIFO and run one
+                            whole MPC step each time (shift, linearisation, RTI chain, nominal update, plant), so no wave slot ever waits for a round or
+                            for another instance; budget_ms / cut_frac are ignored and *rounds_out = 1.  0: the round-based loop described at
+                            slsqp_cl_run.  Same results bit for bit either way. */
 } slsqp_opts;
 
 void slsqp_default_opts(slsqp_opts *o);
@@ -163,8 +167,13 @@ int slsqp_cl_step(slsqp_handle *h, int rti, const double *w, int loc, const slsq
    previous round's deadline suspended; a chain still running budget_ms after its launch started (budget_ms <= 0: no time limit), or still running when
    cut_frac of the round's participants have finished (0 < cut_frac < 1; else off), suspends itself and continues in the next round.
    No instance waits for the slowest one of its step.  Call after slsqp_cl_init (+ slsqp_nominal_solve); per-step results through the device-side
-   log (slsqp_cl_log with max_steps >= steps, before slsqp_cl_init) and `log_qp_stats`[int32] (steps,2,8).  *rounds_out (may be NULL): rounds taken. */
+   log (slsqp_cl_log with max_steps >= steps, before slsqp_cl_init) and `log_qp_stats`[int32] (steps,2,8).  *rounds_out (may be NULL): rounds taken.
+   With opts.cl_persistent (the default) there are no rounds at all: see slsqp_opts. */
 int slsqp_cl_run(slsqp_handle *h, int steps, const double *W, int loc, const slsqp_opts *opts, double budget_ms, double cut_frac, int *rounds_out);
+/* wave statistics of the last persistent slsqp_cl_run: [0] wavefronts launched, [1] sum over the MPC steps of the time a wavefront spent on them (ms),
+   [2] MPC steps run, [3] duration of the launch (ms, HIP events; 0 without opts.time_kernels).  [1] / ([0] x [3]) = how busy the queue kept the waves. */
+#define SLSQP_CL_RUN_STATS_LEN 4
+int slsqp_cl_run_stats(slsqp_handle *h, double *out, int len);
 /* Device-side log of the closed loop: every following slsqp_cl_step stores what the scripts keep per MPC step
    (expe/main_rocket_robust_closed_loop.py:160-178) in entry `step` of (B, max_steps, ...) device buffers, so a Monte-Carlo run makes no
    host round trip per step.  slsqp_get names (per instance): log_state (S,nx) log_u0 (S,nu) log_nominal_x (S,N+1,nx) log_nominal_u (S,N,nu)

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("SLSQP_SO") or os.path.join(_HERE, "csrc", "libslsqp_hip.so")   # SLSQP_SO: experiment builds only
 HOST, DEVICE = 0, 1
-TIMING_LEN, KERNEL_TIMING_LEN = 5, 8      # SLSQP_TIMING_LEN / SLSQP_KERNEL_TIMING_LEN of include/slsqp.h
+TIMING_LEN, KERNEL_TIMING_LEN, CL_RUN_STATS_LEN = 5, 8, 4      # SLSQP_TIMING_LEN / SLSQP_KERNEL_TIMING_LEN / SLSQP_CL_RUN_STATS_LEN of include/slsqp.h
 
 
 class Dims(C.Structure):
@@ -16,14 +16,14 @@ class Dims(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("rti_steps", C.c_int), ("max_sls_iter", C.c_int), ("qp_max_iter", C.c_int), ("qp_eps", C.c_double),
                 ("conv_tol", C.c_double), ("eps_backoff", C.c_double), ("want_K", C.c_int), ("warm_start", C.c_int), ("warm_rounds", C.c_int),
-                ("max_scp_iter", C.c_int), ("scp_eps", C.c_double), ("precision", C.c_int), ("as_first", C.c_int), ("as_rounds", C.c_int), ("as_max_viol", C.c_int), ("ipm_restart", C.c_int), ("time_kernels", C.c_int), ("as_warm_max_set", C.c_int), ("as_warm_last", C.c_int), ("fuse_rti", C.c_int)]
+                ("max_scp_iter", C.c_int), ("scp_eps", C.c_double), ("precision", C.c_int), ("as_first", C.c_int), ("as_rounds", C.c_int), ("as_max_viol", C.c_int), ("ipm_restart", C.c_int), ("time_kernels", C.c_int), ("as_warm_max_set", C.c_int), ("as_warm_last", C.c_int), ("fuse_rti", C.c_int), ("cl_persistent", C.c_int)]
 
 
 EXPORTS = [
     "slsqp_default_opts", "slsqp_last_error", "slsqp_version", "slsqp_create", "slsqp_destroy", "slsqp_set_costs",
     "slsqp_set_constraints", "slsqp_update_dynamics", "slsqp_update_linear_cost", "slsqp_solve", "slsqp_get", "slsqp_reset",
     "slsqp_sync", "slsqp_qp_nnz", "slsqp_qp_update_data_mat", "slsqp_qp_update_data_vec", "slsqp_qp_solve", "slsqp_sweep",
-    "slsqp_last_timing", "slsqp_kernel_timing", "slsqp_stream", "slsqp_set_model", "slsqp_set_E", "slsqp_linearize", "slsqp_cl_init", "slsqp_cl_step", "slsqp_nominal_solve", "slsqp_set", "slsqp_cl_log", "slsqp_selftest", "slsqp_result_bytes", "slsqp_cl_run",
+    "slsqp_last_timing", "slsqp_kernel_timing", "slsqp_stream", "slsqp_set_model", "slsqp_set_E", "slsqp_linearize", "slsqp_cl_init", "slsqp_cl_step", "slsqp_nominal_solve", "slsqp_set", "slsqp_cl_log", "slsqp_selftest", "slsqp_result_bytes", "slsqp_cl_run", "slsqp_cl_run_stats",
 ]
 
 _lib = None
@@ -78,6 +78,7 @@ def load():
     lib.slsqp_nominal_solve.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.POINTER(Opts)]
     lib.slsqp_cl_log.argtypes = [vp, C.c_int]
     lib.slsqp_cl_run.argtypes = [vp, C.c_int, dp, C.c_int, C.POINTER(Opts), C.c_double, C.c_double, C.POINTER(C.c_int)]
+    lib.slsqp_cl_run_stats.argtypes = [vp, dp, C.c_int]
     lib.slsqp_selftest.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int]
     lib.slsqp_stream.argtypes = [vp]
     lib.slsqp_stream.restype = vp

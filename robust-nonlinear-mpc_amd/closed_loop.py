@@ -114,8 +114,10 @@ class ClosedLoopMPC:
     def run_decoupled(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False, continuation=1, budget_ms=8.0, cut_frac=0.0):
         """Same results as run_on_device() -- bit for bit -- through slsqp_cl_run: the instances advance through their MPC steps independently (a
         chain of QP solves that is not done budget_ms after its launch started suspends itself and resumes in the next round), so nobody waits for the
-        slowest instance of a step.  Only for the rocket script's setting (rti = 1, one fast-SLS step, fp64).  Adds `qp_stats` (B, steps, 2, 8) and
-        `rounds`; the t_* arrays hold the run's totals in their first entry."""
+        slowest instance of a step.  With opts.cl_persistent (the default) the whole loop is ONE launch: waves take instances from a device-side
+        FIFO and run one MPC step each time; budget_ms / cut_frac only matter for opts.cl_persistent = 0.  Only for the rocket script's setting
+        (rti = 1, one fast-SLS step, fp64).  Adds `qp_stats` (B, steps, 2, 8), `rounds` and (persistent) `loop_stats`; the t_* arrays hold the
+        run's totals in their first entry."""
         f, m, N, B = self.f, self.m, self.N, self.B
         assert self.rti == 1, "slsqp_cl_run runs rti = 1 closed loops"
         L.check(f.lib.slsqp_cl_log(f.h, int(steps)))
@@ -131,6 +133,10 @@ class ClosedLoopMPC:
         out = self._log_result(steps, t_jac, t_qp, t_ric)
         out["qp_stats"] = f.get("log_qp_stats", (steps, 2, 8), np.int32)
         out["rounds"] = rounds.value
+        if f.opts.cl_persistent:      # one persistent launch: how busy the instance queue kept the waves
+            st = (C.c_double * L.CL_RUN_STATS_LEN)()
+            L.check(f.lib.slsqp_cl_run_stats(f.h, st, L.CL_RUN_STATS_LEN))
+            out["loop_stats"] = dict(waves=int(st[0]), busy_ms=float(st[1]), mpc_steps=int(st[2]), launch_ms=float(st[3]))
         return out
 
     def run(self, x0, steps, W=None, X_nom=None, U_nom=None, solve_nominal=False):

@@ -59,16 +59,42 @@ DYN_HD double matan(double a) { return atan(a); }
 DYN_HD double val(double a) { return a; }
 DYN_HD double val(Dual a) { return a.v; }
 
+// ---- how an ODE evaluation gets its transcendental functions ------------------------------------------------------
+// MathPlain computes them.  The linearisation evaluates the ODE at the same four RK4 points once in plain doubles (ddyn_stages) and then once
+// per direction in dual numbers (ddyn_tangent: 21 directions for the rocket): the sines, cosines, arctangents and square roots of the primal
+// are the same every time, and they are most of the instructions (and of the registers) of an evaluation.  MathRecord (doubles) computes them and
+// keeps them on a tape, in call order; MathReplay (dual numbers) reads the primal values back from the tape and only forms the derivative
+// parts.  The tape entries per evaluation: Dims<MODEL>::NT.
+struct MathPlain {
+    template <typename T> DYN_HD void sincos(T a, T &s, T &c) { msincos(a, s, c); }
+    template <typename T> DYN_HD T sqrt(T a) { return msqrt(a); }
+    template <typename T> DYN_HD T atan(T a) { return matan(a); }
+};
+struct MathRecord {
+    double *tape; int n;
+    DYN_HD explicit MathRecord(double *t) : tape(t), n(0) {}
+    DYN_HD void sincos(double a, double &s, double &c) { msincos(a, s, c); tape[n++] = s; tape[n++] = c; }
+    DYN_HD double sqrt(double a) { const double r = msqrt(a); tape[n++] = r; return r; }
+    DYN_HD double atan(double a) { const double r = matan(a); tape[n++] = r; return r; }
+};
+struct MathReplay {
+    const double *tape; int n;
+    DYN_HD explicit MathReplay(const double *t) : tape(t), n(0) {}
+    DYN_HD void sincos(Dual a, Dual &s, Dual &c) { const double sv = tape[n++], cv = tape[n++]; s = Dual(sv, cv * a.d); c = Dual(cv, -sv * a.d); }
+    DYN_HD Dual sqrt(Dual a) { const double r = tape[n++]; return Dual(r, 0.5 * a.d / r); }
+    DYN_HD Dual atan(Dual a) { const double r = tape[n++]; return Dual(r, a.d / (1.0 + a.v * a.v)); }
+};
+
 constexpr int MODEL_PENDULUM = 0, MODEL_QUADROTOR = 1, MODEL_ROCKET = 2;
 constexpr double RK4_H = 0.05;
 
 // ---- ODEs ---------------------------------------------------------------------------------------------------------
-template <typename T>
-DYN_HD void ode_pendulum(const T *X, const T *U, T *dX) {
+template <typename T, typename M>
+DYN_HD void ode_pendulum(const T *X, const T *U, T *dX, M &mf) {
     const T xd = X[1], th = X[2], thd = X[3], u = U[0];
     const double m1 = 1.0, m2 = 0.1, l = 0.5, g = 9.81;
     T s, c;
-    msincos(th, s, c);
+    mf.sincos(th, s, c);
     const T den = T(m1) + T(m2) * (T(1.0) - c * c);
     const T xdd = (u + T(m2 * l) * thd * thd * s - T(m2 * g) * s * c) / den;
     const T thdd = (-u * c - T(m2 * l) * thd * thd * s * c + T((m1 + m2) * g) * s) / (T(l) * den);
@@ -87,8 +113,8 @@ DYN_HD void rot_apply(T qw, T qx, T qy, T qz, T bx, T by, T bz, T &wx, T &wy, T 
     wz = r20 * bx + r21 * by + r22 * bz;
 }
 
-template <typename T>
-DYN_HD void ode_quadrotor(const T *X, const T *U, T *dX) {
+template <typename T, typename M>
+DYN_HD void ode_quadrotor(const T *X, const T *U, T *dX, M &) {
     const double m = 1.0, g = 9.81, l = 0.15, Jx = 0.02, Jy = 0.02, Jz = 0.04, kM = 0.01;
     const T qw = X[6], qx = X[7], qy = X[8], qz = X[9], wx = X[10], wy = X[11], wz = X[12];
     const T f1 = U[0], f2 = U[1], f3 = U[2], f4 = U[3];
@@ -110,31 +136,31 @@ DYN_HD void ode_quadrotor(const T *X, const T *U, T *dX) {
     dX[12] = (tz - (wx * Jwy - wy * Jwx)) * T(1.0 / Jz);
 }
 
-template <typename T>
-DYN_HD T gimbal_angle(T servo, T cos_tilt) {   // rocket.py:246-254; takes cos(tilt_axis_angle): the caller has it already
+template <typename T, typename M>
+DYN_HD T gimbal_angle(T servo, T cos_tilt, M &mf) {   // rocket.py:246-254; takes cos(tilt_axis_angle): the caller has it already
     const double a = 5.0, b = 35.2, c = 33.0, d = 28.0, e = 35.2;
     T ss, cs;
-    msincos(servo, ss, cs);
+    mf.sincos(servo, ss, cs);
     const T iv1 = T(d) + T(a) * cs;
     const T iv2 = T(e) - T(a) * ss;
     const T u = T(b * b - c * c) - iv1 * iv1 - iv2 * iv2;
     const T v = T(2.0 * c) * cos_tilt * iv2;
     const T w = T(-2.0 * c) * iv1;
     const T iv3 = w * w + v * v - u * u;
-    return T(2.0) * matan((v - msqrt(iv3)) / (u + w));
+    return T(2.0) * mf.atan((v - mf.sqrt(iv3)) / (u + w));
 }
 
-template <typename T>
-DYN_HD void ode_rocket(const T *X, const T *U, T *dX) {
+template <typename T, typename M>
+DYN_HD void ode_rocket(const T *X, const T *U, T *dX, M &mf) {
     const double mass = 1.16, grav = 9.81, Jxx = 0.00210, Jyy = 0.1, Jzz = 0.1, off = 0.42, tau_t = 0.06, tau_s = 0.10, hover = 11.3796;
     const T qw = X[6], qx = X[7], qy = X[8], qz = X[9], wx = X[10], wy = X[11], wz = X[12];
     const T thrust = X[13] + T(hover), torque_x = X[14], sa1 = X[15], sa2 = X[16];
     const T thrust_in = U[0] + T(hover), torque_in = U[1], sa1_in = U[2], sa2_in = U[3];
     T s1, c1, s2, c2;
-    const T g1 = gimbal_angle(sa1, T(1.0));
-    msincos(g1, s1, c1);
-    const T g2 = gimbal_angle(sa2, c1);
-    msincos(g2, s2, c2);
+    const T g1 = gimbal_angle(sa1, T(1.0), mf);
+    mf.sincos(g1, s1, c1);
+    const T g2 = gimbal_angle(sa2, c1, mf);
+    mf.sincos(g2, s2, c2);
     const T Bx = -thrust * s1 * c2, By = thrust * s2, Bz = thrust * c1 * c2;
     T ax, ay, az;
     rot_apply(qw, qx, qy, qz, Bx, By, Bz, ax, ay, az);
@@ -157,16 +183,20 @@ DYN_HD void ode_rocket(const T *X, const T *U, T *dX) {
 }
 
 template <int MODEL> struct Dims;
-template <> struct Dims<MODEL_PENDULUM> { static constexpr int NX = 4, NU = 1; };
-template <> struct Dims<MODEL_QUADROTOR> { static constexpr int NX = 13, NU = 4; };
-template <> struct Dims<MODEL_ROCKET> { static constexpr int NX = 17, NU = 4; };
+// NT: transcendental values one ODE evaluation puts on the tape (pendulum: sin, cos; rocket: 2 x (sin, cos, sqrt, atan) of the gimbal linkage + 2 x (sin, cos))
+template <> struct Dims<MODEL_PENDULUM> { static constexpr int NX = 4, NU = 1, NT = 2; };
+template <> struct Dims<MODEL_QUADROTOR> { static constexpr int NX = 13, NU = 4, NT = 0; };
+template <> struct Dims<MODEL_ROCKET> { static constexpr int NX = 17, NU = 4, NT = 12; };
+constexpr int NT_MAX = 12;
 
-template <int MODEL, typename T>
-DYN_HD void ode(const T *X, const T *U, T *dX) {
-    if (MODEL == MODEL_PENDULUM) ode_pendulum<T>(X, U, dX);
-    else if (MODEL == MODEL_QUADROTOR) ode_quadrotor<T>(X, U, dX);
-    else ode_rocket<T>(X, U, dX);
+template <int MODEL, typename T, typename M>
+DYN_HD void ode(const T *X, const T *U, T *dX, M &mf) {
+    if (MODEL == MODEL_PENDULUM) ode_pendulum<T, M>(X, U, dX, mf);
+    else if (MODEL == MODEL_QUADROTOR) ode_quadrotor<T, M>(X, U, dX, mf);
+    else ode_rocket<T, M>(X, U, dX, mf);
 }
+template <int MODEL, typename T>
+DYN_HD void ode(const T *X, const T *U, T *dX) { MathPlain mf; ode<MODEL, T, MathPlain>(X, U, dX, mf); }
 
 // x+ = RK4(x, u), h = 0.05   (dyn/model.py:27-32); k's are accumulated on the fly to keep the register footprint small
 template <int MODEL, typename T>
@@ -188,23 +218,24 @@ DYN_HD void ddyn(const T *X, const T *U, T *Xp) {
 // through the whole RK4 step carries X, k, t, acc as duals: 288 registers for the rocket, 189 of them spilled in round 1's kernel):
 // (1) ddyn_stages: the plain RK4 step, keeping the three intermediate stage points; (2) ddyn_tangent: the tangent of the step along one
 // direction, the stage points' values read back instead of carried.
+// tape (4 * Dims<MODEL>::NT doubles; may be NULL when NT == 0): the transcendental values of the four evaluations, for ddyn_tangent
 template <int MODEL>
-DYN_HD void ddyn_stages(const double *x, const double *u, double *stage /* 3*NX: x + h/2 k1, x + h/2 k2, x + h k3 */, double *xp) {
-    constexpr int NX = Dims<MODEL>::NX;
+DYN_HD void ddyn_stages(const double *x, const double *u, double *stage /* 3*NX: x + h/2 k1, x + h/2 k2, x + h k3 */, double *xp, double *tape) {
+    constexpr int NX = Dims<MODEL>::NX, NT = Dims<MODEL>::NT;
     const double h = RK4_H;
     double k[NX], t[NX], acc[NX];
-    ode<MODEL, double>(x, u, k);
+    { MathRecord mf(tape); ode<MODEL, double, MathRecord>(x, u, k, mf); }
     for (int i = 0; i < NX; i++) { acc[i] = k[i]; t[i] = x[i] + 0.5 * h * k[i]; stage[i] = t[i]; }
-    ode<MODEL, double>(t, u, k);
+    { MathRecord mf(tape + NT); ode<MODEL, double, MathRecord>(t, u, k, mf); }
     for (int i = 0; i < NX; i++) { acc[i] = acc[i] + 2.0 * k[i]; t[i] = x[i] + 0.5 * h * k[i]; stage[NX + i] = t[i]; }
-    ode<MODEL, double>(t, u, k);
+    { MathRecord mf(tape + 2 * NT); ode<MODEL, double, MathRecord>(t, u, k, mf); }
     for (int i = 0; i < NX; i++) { acc[i] = acc[i] + 2.0 * k[i]; t[i] = x[i] + h * k[i]; stage[2 * NX + i] = t[i]; }
-    ode<MODEL, double>(t, u, k);
+    { MathRecord mf(tape + 3 * NT); ode<MODEL, double, MathRecord>(t, u, k, mf); }
     for (int i = 0; i < NX; i++) xp[i] = x[i] + (1.0 / 6.0) * (acc[i] + k[i]) * h;
 }
 template <int MODEL>
-DYN_HD void ddyn_tangent(const double *x, const double *u, const double *stage, int dir, double *col) {
-    constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
+DYN_HD void ddyn_tangent(const double *x, const double *u, const double *stage, const double *tape, int dir, double *col) {
+    constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU, NT = Dims<MODEL>::NT;
     const double h = RK4_H;
     Dual T[NX], U[NU], K[NX];
     double acc[NX];
@@ -212,7 +243,7 @@ DYN_HD void ddyn_tangent(const double *x, const double *u, const double *stage, 
     for (int i = 0; i < NX; i++) { T[i] = Dual(x[i], i == dir ? 1.0 : 0.0); acc[i] = 0.0; }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        ode<MODEL, Dual>(T, U, K);
+        { MathReplay mf(tape + s * NT); ode<MODEL, Dual, MathReplay>(T, U, K, mf); }
         const double w = (s == 0 || s == 3) ? 1.0 : 2.0, cn = (s == 2) ? h : 0.5 * h;
         for (int i = 0; i < NX; i++) {
             acc[i] += w * K[i].d;

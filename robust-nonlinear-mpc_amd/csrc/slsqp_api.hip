@@ -32,7 +32,7 @@ extern "C" const char *slsqp_version(void) { return "slsqp-hip 0.1 (gfx950)"; }
 extern "C" void slsqp_default_opts(slsqp_opts *o) {
     o->rti_steps = 1; o->max_sls_iter = 30; o->qp_max_iter = 60; o->qp_eps = 1e-6; o->conv_tol = 1e-3;
     o->eps_backoff = 1e-10; o->want_K = 1; o->warm_start = 1; o->warm_rounds = 20;
-    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0; o->as_first = 2; o->as_rounds = 24; o->as_max_viol = 64; o->ipm_restart = 1; o->as_warm_max_set = 28; o->as_warm_last = 1; o->fuse_rti = 1;
+    o->max_scp_iter = 100; o->scp_eps = 1e-10; o->precision = 0; o->time_kernels = 0; o->as_first = 2; o->as_rounds = 24; o->as_max_viol = 64; o->ipm_restart = 1; o->as_warm_max_set = 28; o->as_warm_last = 1; o->fuse_rti = 1; o->cl_persistent = 1;
 }
 
 struct slsqp_handle {
@@ -56,13 +56,14 @@ struct slsqp_handle {
     // start-time word, the per-step copy of qp_stats
     int *cl_stepno = nullptr, *cl_lag = nullptr, *cl_begin = nullptr, *cl_runm = nullptr, *cl_done = nullptr, *cl_skipb = nullptr, *cl_skip_begin = nullptr, *qplog = nullptr;
     double *call_ids = nullptr, *cl_W = nullptr; size_t cl_W_doubles = 0; unsigned long long *t0word = nullptr; int qplog_steps = 0;
+    int *clq_slots = nullptr, *clq_ctl = nullptr; unsigned clq_cap = 0; int cl_loop_waves = 0; double cl_loop_ms = 0.0; unsigned long long *cl_busy = nullptr, *cl_tbegin = nullptr, cl_busy_host[16] = {};      // k_cl_loop: instance FIFO (slots; head, tail, avail, err), wave life-time counters
     bool cl_round = false; unsigned long long cl_budget = 0; int cl_total_steps = 0; unsigned cl_cut_count = 0xFFFFFFFFu;
     unsigned long long *chain_times = nullptr, *chain_times_host = nullptr;   // (B,4) in-kernel wall-clock ticks per instance; pinned copy of instance 0's
     int *qp_diag = nullptr;     // QP_DIAG_SPAN builds only
     double *nom_st; int *nom_need_lin, *nom_status, *nom_iters;
     int *retry; int mx_retry, mx_retry_total;
     double *Kc, *Aclc;          // (B,N,nu,nx), (B,N,nx,nx): K_k and A_k + B_k K_k of the shared Riccati recursion (k_sweep_ric1 -> k_sweep_prop)
-    double *lin_stage;          // (B,N,3,nx) intermediate RK4 stage points of the linearisation (k_lin_val -> k_lin_tan)
+    double *lin_stage, *lin_tape;   // (B,N,3,nx) intermediate RK4 stage points of the linearisation (k_lin_val -> k_lin_tan); (B,N,4,NT_MAX) its transcendental values
     double call_id;             // counts fast-SLS calls (validity of the interior-point iterate copies, QpArgs::call_id)
     int *qpstat;                // (B,2,8) per-QP statistics, see QpArgs::qpstat
     int *stale;                 // (B) bit 0: eta / eta_f, bit 1: K hold values from before the last slsqp_reset (zeroed lazily on slsqp_get)
@@ -169,8 +170,9 @@ extern "C" slsqp_handle *slsqp_create(const slsqp_dims *d, int batch, int device
     rc |= dalloc(h->owned, &h->mapA, (size_t)N * nx * nx); rc |= dalloc(h->owned, &h->mapB, (size_t)N * nx * nu);
     rc |= dalloc(h->owned, &h->inst_launches, (size_t)8); rc |= dalloc(h->owned, &h->chain_times, B * 4);
     rc |= dalloc(h->owned, &h->cl_stepno, B); rc |= dalloc(h->owned, &h->cl_lag, B); rc |= dalloc(h->owned, &h->cl_begin, B); rc |= dalloc(h->owned, &h->cl_runm, B); rc |= dalloc(h->owned, &h->cl_done, B);
+    { unsigned cap = 1; while (cap < 4u * (unsigned)B) cap <<= 1; h->clq_cap = cap; rc |= dalloc(h->owned, &h->clq_slots, (size_t)cap); rc |= dalloc(h->owned, &h->clq_ctl, (size_t)8); rc |= dalloc(h->owned, &h->cl_busy, (size_t)16); rc |= dalloc(h->owned, &h->cl_tbegin, (size_t)B); }
     rc |= dalloc(h->owned, &h->cl_skipb, B); rc |= dalloc(h->owned, &h->call_ids, B); rc |= dalloc(h->owned, &h->t0word, (size_t)2); rc |= dalloc(h->owned, &h->ct_part, B * (N + 1)); rc |= dalloc(h->owned, &h->cost_tube, B);
-    rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->Kc, B * N * nu * nx); rc |= dalloc(h->owned, &h->Aclc, B * N * nx * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->Gd, (size_t)ni * (nx + nu)); rc |= dalloc(h->owned, &h->Gfd, (size_t)nif * nx); h->general_G = false; h->beta_inited = false; rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
+    rc |= dalloc(h->owned, &h->lin_stage, B * N * 3 * nx); rc |= dalloc(h->owned, &h->lin_tape, B * N * 4 * dyn::NT_MAX); rc |= dalloc(h->owned, &h->Kc, B * N * nu * nx); rc |= dalloc(h->owned, &h->Aclc, B * N * nx * nx); rc |= dalloc(h->owned, &h->qpstat, B * 16); rc |= dalloc(h->owned, &h->Gd, (size_t)ni * (nx + nu)); rc |= dalloc(h->owned, &h->Gfd, (size_t)nif * nx); h->general_G = false; h->beta_inited = false; rc |= dalloc(h->owned, &h->stale, B); rc |= dalloc(h->owned, &h->pinf, B); rc |= dalloc(h->owned, &h->scp_upd, B); h->t_jac = 0;
     h->log_steps = 0; h->lg_x = h->lg_u = h->lg_bx = h->lg_bu = h->lg_state = h->lg_u0 = h->lg_pinf = nullptr; h->lg_succ = h->lg_it = nullptr;
     if (rc) { free_all(h->owned); hipStreamDestroy(h->st); delete h; return nullptr; }
     if (hipHostMalloc((void **)&h->chain_times_host, 4 * sizeof(unsigned long long)) != hipSuccess) h->chain_times_host = nullptr;
@@ -569,11 +571,7 @@ struct ChainArgs {
     int *qplog; const int *stepno; int log_steps;      // (B, log_steps, 16) per-step copy of the instance's qp_stats, entry stepno[b]
 };
 template <int NX, int NU>
-__global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_rti_chain(ChainArgs c) {
-    int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= c.q1.B) return;
-    if (c.runm && !c.runm[b]) return;
-    extern __shared__ double sm[];
+__device__ __forceinline__ int rti_chain_dev(const ChainArgs &c, int b, int lane, double *sm) {
     unsigned long long t0 = wall_clock64(), t1 = t0, t2 = t0, deadline = ~0ULL;
     int lg = 0;
     if (c.lag) {
@@ -611,7 +609,7 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_rti_chain(Cha
         }
         t2 = wall_clock64();
     }
-    if (!fin) return;
+    if (!fin) return 0;
     if (lane == 0) {
         if (c.active && !c.active[b]) c.success[b] = 0;
         else c.success[b] = (!c.infeas[b]) || c.success[b];           // fast_SLS_jit.py:295 (k_finish, RTI)
@@ -619,6 +617,182 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_rti_chain(Cha
         if (c.lag) { c.lag[b] = 0; c.done[b] = 1; atomicAdd(c.fin_count, 1u); }
     }
     if (c.qplog && lane < 16) c.qplog[((size_t)b * c.log_steps + min(c.stepno[b], c.log_steps - 1)) * 16 + lane] = c.q1.qpstat[(size_t)b * 16 + lane];
+    return 1;
+}
+template <int NX, int NU>
+__global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_rti_chain(ChainArgs c) {
+    int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= c.q1.B) return;
+    if (c.runm && !c.runm[b]) return;
+    extern __shared__ double sm[];
+    rti_chain_dev<NX, NU>(c, b, lane, sm);
+}
+
+// ---- the whole closed loop as ONE persistent launch (slsqp_cl_run, opts.cl_persistent) ------------------------------------------------
+// A wave takes an instance from a device-side FIFO, runs ONE complete MPC step of it -- warm-start shift, solver reset, linearisation, x0 pin,
+// solve start, the RTI chain (QP #1 -> eta -> Riccati / propagation -> tightened bounds -> QP #2), nominal update, primal infeasibility, log
+// entry, plant step with the disturbance sample of that step -- and puts the instance back while it has steps left.  Every step of every
+// instance is the same sequence of device functions the launches of slsqp_cl_step run (same arithmetic, same bits); what is gone is every
+// barrier between instances: no wave slot waits for a round, a deadline or the slowest instance of a batch, and the FIFO order keeps the
+// instances' step counters together so the run has no long tail.  The queue: slots[cap] (0 = empty, else instance + 1), tail / head
+// tickets, `avail` = published items not yet claimed.  A wave that finds avail <= 0 EXITS (an instance is always either in the queue or
+// held by a running wave, which will push and then pop again; so nothing is stranded); the only waits are for the slot of a ticket already
+// taken to be published / cleared by a wave that is a few instructions away from doing so, and they are bounded (err flag instead of a hang).
+// Hand-over between waves on different XCDs (own L2 each): agent-scope release before the push, acquire after the pop.
+struct ClQueue { int *slots; unsigned mask; unsigned *head, *tail; int *avail, *err; };
+__device__ __forceinline__ int clq_pop(const ClQueue &q, int lane) {
+    int v = -1;
+    if (lane == 0) {
+        const int av = atomicSub(q.avail, 1);
+        if (av <= 0) atomicAdd(q.avail, 1);
+        else {
+            const unsigned t = atomicAdd(q.head, 1u);
+            int *slot = q.slots + (t & q.mask);
+            int got = 0;
+            for (int spin = 0; spin < (1 << 22) && !got; spin++) {
+                got = __hip_atomic_exchange(slot, 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (!got) __builtin_amdgcn_s_sleep(4);
+            }
+            if (got) v = got - 1; else atomicExch(q.err, 1);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void clq_push(const ClQueue &q, int b, int lane) {
+    if (lane == 0) {
+        const unsigned p = atomicAdd(q.tail, 1u);
+        int *slot = q.slots + (p & q.mask);
+        bool ok = false;
+        for (int spin = 0; spin < (1 << 22) && !ok; spin++) {
+            int expected = 0;
+            ok = __hip_atomic_compare_exchange_strong(slot, &expected, b + 1, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!ok) __builtin_amdgcn_s_sleep(4);
+        }
+        if (ok) atomicAdd(q.avail, 1); else atomicExch(q.err, 2);
+    }
+}
+__global__ void k_clq_init(int B, ClQueue q) {
+    const unsigned cap = q.mask + 1u;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) q.slots[i] = (i < (unsigned)B) ? (int)i + 1 : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *q.head = 0u; *q.tail = (unsigned)B; *q.avail = B; *q.err = 0; }
+}
+// k_solve_begin for one wave
+__device__ __forceinline__ void solve_begin_wave(const SolveBeginArgs &a, int b, int lane) {
+    const int act = a.active ? a.active[b] : 1;
+    if (a.x0 && lane < a.NX) a.x0val[(size_t)b * a.NX + lane] = -a.x0[(size_t)b * a.NX + lane];
+    const int pend = a.pending[b];
+    wla::wsync_mem();
+    if (lane == 0) { a.alive[b] = act; a.infeas[b] = 0; a.success[b] = 0; }
+    if (pend && act) {       // _finish_failure of the previous call (fast_SLS_jit.py:334-341)
+        for (size_t o = lane; o < a.neta; o += 64) a.eta[(size_t)b * a.neta + o] = 0.0;
+        for (size_t o = lane; o < a.netaf; o += 64) a.eta_f[(size_t)b * a.netaf + o] = 0.0;
+        const int st = a.stale[b];
+        wla::wsync_mem();
+        if (lane == 0) { a.itnum[b] = 0; a.pending[b] = 0; a.stale[b] = st & ~16; }
+    }
+    const InitBackoffArgs &i = a.ib;
+    if (i.run && !i.run[b]) return;
+    const int NZ = i.NX + i.NU, NI = 2 * NZ, NIF = 2 * i.NX, N = i.N;
+    const double sq = sqrt(i.eps);
+    for (int o = lane; o < N * NI; o += 64) i.backoff[(size_t)b * N * NI + o] = N * sq;
+    for (int o = lane; o < NIF; o += 64) i.backoff_f[(size_t)b * NIF + o] = (N + 1) * sq;
+    for (int o = lane; o < (N + 1) * i.NX; o += 64) i.backoff_x[(size_t)b * (N + 1) * i.NX + o] = 0.0;
+    for (int o = lane; o < N * i.NU; o += 64) i.backoff_u[(size_t)b * N * i.NU + o] = 0.0;
+}
+struct LoopArgs {
+    ChainArgs c; ClArgs cl; LinArgs lin; BoundsArgs ba; SolveBeginArgs sb; ClLogArgs lg; ScpArgs sa;
+    int steps, n, have_log, fence;
+    int *stepno; double *call_ids, *q; int *stale, *itnum, *pending, *scp_active;
+    const double *W_all; double *pinf;
+    ClQueue Q;
+    unsigned long long *busy, *t_begin;      // busy[0] sum over the MPC steps of the time a wave spent on them (100 MHz ticks), [2] MPC steps run; t_begin (B): start of the instance's current step
+};
+// the two halves of an MPC step around the RTI chain, as functions of their own: what they keep in registers (dual numbers of the linearisation, the
+// plant's RK4 stages) stays out of the register allocation of the QP loops, and nothing of theirs is live across the chain
+template <int MODEL>
+__device__ CLW_FN void cl_step_begin(const LoopArgs &L, int b, int lane) {
+    constexpr int NX = dyn::Dims<MODEL>::NX;
+    const int s = L.stepno[b];
+    if (lane == 0) L.t_begin[b] = wall_clock64();
+#ifdef CL_LOOP_STAMP
+    unsigned long long ts_ = wall_clock64();
+#define CLSTAMP(i) do { wla::wsync_mem(); const unsigned long long t_ = wall_clock64(); if (lane == 0) atomicAdd(L.busy + (i), t_ - ts_); ts_ = t_; } while (0)
+#else
+#define CLSTAMP(i) do {} while (0)
+#endif
+    // reset_warm_start (shift + solver reset) past the first step, call id, flags
+    if (s > 0) {
+        cl_shift_wave<MODEL>(L.cl, b, lane);
+        for (int o = lane; o < L.n; o += 64) L.q[(size_t)b * L.n + o] = 0.0;
+        const int st = L.stale[b];
+        wla::wsync_mem();
+        if (lane == 0) { L.stale[b] = (st & 8) | 3; L.itnum[b] = 0; L.pending[b] = 0; }
+    }
+    if (lane == 0) { L.call_ids[b] += 1.0; L.sa.scp_success[b] = 0; L.sa.scp_iters[b] = 0; }
+    wla::wsync_mem();
+    CLSTAMP(4);
+    lin_wave<MODEL>(L.lin, L.ba, b, lane);
+    CLSTAMP(5);
+    if (lane < NX) L.cl.x0arg[(size_t)b * NX + lane] = L.cl.Xn[(size_t)b * (L.cl.N + 1) * NX + lane] - L.cl.xmeas[(size_t)b * NX + lane];
+    wla::wsync_mem();
+    solve_begin_wave(L.sb, b, lane);
+    wla::wsync_mem();
+    CLSTAMP(6);
+}
+// nominal += delta, primal infeasibility, log entry, plant + noise, step counter; returns 1 while the instance has steps left
+template <int MODEL>
+__device__ CLW_FN int cl_step_end(const LoopArgs &L, int b, int lane) {
+    constexpr int NX = dyn::Dims<MODEL>::NX;
+    const int s = L.stepno[b];
+#ifdef CL_LOOP_STAMP
+    unsigned long long ts_ = wall_clock64();
+#endif
+    if (lane == 0) L.scp_active[b] = 1;
+    wla::wsync_mem();
+    cl_scp_update_wave(L.cl, L.sa, b, lane);
+    wla::wsync_mem();
+    CLSTAMP(7);
+    if (L.sa.updated[b]) cl_infeas_wave<MODEL>(L.cl, L.pinf, b, lane);
+    wla::wsync_mem();
+    CLSTAMP(8);
+    if (L.have_log) {
+        const int per = 2 * ((L.lg.N + 1) * L.lg.NX + L.lg.N * L.lg.NU);
+        for (int o = lane; o < per; o += 64) cl_log_item(L.lg, b, o);
+    }
+    CLSTAMP(9);
+    if (lane == 0) {
+        cl_plant_one<MODEL>(L.cl, b, L.W_all ? L.W_all + (size_t)s * L.cl.B * NX : nullptr);
+        L.stepno[b] = s + 1;
+        if (L.busy) { atomicAdd(L.busy, wall_clock64() - L.t_begin[b]); atomicAdd(L.busy + 2, 1ULL); }
+    }
+    wla::wsync_mem();
+    CLSTAMP(10);
+    return (s + 1 < L.steps) ? 1 : 0;
+}
+template <int MODEL>
+__global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_cl_loop(LoopArgs L) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
+    int lane = threadIdx.x;
+    extern __shared__ double sm[];
+#pragma unroll 1
+    for (;;) {
+        asm volatile("" : "+v"(lane));
+        int b = clq_pop(L.Q, lane);
+        if (b < 0) break;
+        if (L.fence & 1) __threadfence();      // acquire: what the wave that ran this instance's previous step wrote (possibly through another XCD's L2)
+        cl_step_begin<MODEL>(L, b, lane);
+        b = __builtin_amdgcn_readfirstlane(b);      // (across a call the compiler may park it in a vector register)
+        asm volatile("" : "+v"(lane));
+        rti_chain_dev<NX, NU>(L.c, b, lane, sm);
+        wla::wsync_mem();
+        asm volatile("" : "+v"(lane));
+        const int more = __builtin_amdgcn_readfirstlane(cl_step_end<MODEL>(L, b, lane));
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (more) {
+            if (L.fence & 2) __threadfence();      // release: the next step of this instance may run anywhere
+            clq_push(L.Q, b, lane);
+        }
+    }
 }
 
 // ---- masked pieces of a closed-loop round (slsqp_cl_run) ----
@@ -725,7 +899,7 @@ static QpArgs make_qp_args(slsqp_handle *h, const int *run, const slsqp_opts *o,
     static const double snap_mu = getenv("SLSQP_SNAP_MU") ? atof(getenv("SLSQP_SNAP_MU")) : 1e-3;
     a.snap_take = snap_take; a.snap_use = snap_use && o->ipm_restart; a.snap_mu = snap_mu; a.call_id = h->call_id; a.call_ids = h->cl_round ? h->call_ids : nullptr; a.as_first = o->as_first; a.as_rounds = o->as_rounds; a.as_max_viol = o->as_max_viol; a.as_warm_max_set = o->as_warm_max_set; a.as_warm_last = o->as_warm_last;
     { static const double pe = getenv("SLSQP_PINF_EPS") ? atof(getenv("SLSQP_PINF_EPS")) : 1e-4; a.pinf_eps = pe; }
-    { static const int ws = getenv("SLSQP_WARM_SHIFT") ? atoi(getenv("SLSQP_WARM_SHIFT")) : 1; a.warm_shift = ws ? warm_shift : 0; }
+    { static const int ws = getenv("SLSQP_WARM_SHIFT") ? atoi(getenv("SLSQP_WARM_SHIFT")) : 1; a.warm_shift = ws ? warm_shift : 0; a.shift_stepno = nullptr; }
     a.prox = prox; a.prox_stride = 12; a.inst_launches = h->inst_launches;
     a.B = h->B; a.N = h->d.N; a.A = h->A; a.Bm = h->Bm; a.q = h->q; a.ubg = h->ubg; a.lbg = h->lbg; a.x0val = h->x0val; a.run = run;
     a.cst = costs_of(h); a.Linv = h->Linv; a.ws = h->ws; a.primal = h->primal; a.dual = h->dual; a.cost = h->cost; a.pin_dual = h->pin_dual; a.kkt = h->kkt;
@@ -809,6 +983,28 @@ static int launch_sweep(slsqp_handle *h, const int *run, const double *eta, cons
     SLSQP_DIM_LIST
 #undef X
     return -1;
+}
+
+// arguments of one RTI chain (k_rti_chain / k_cl_loop): QP #1, what follows it, the sweep, the tightening, QP #2
+static int qp_max_ticks(const QpArgs &a, int max_iter);
+static ChainArgs make_chain_args(slsqp_handle *h, const slsqp_opts &o, const int *active, int wshift) {
+    const slsqp_dims &d = h->d;
+    const int B = h->B;
+    ChainArgs c;
+    c.q1 = make_qp_args(h, h->alive, &o, o.warm_start ? 1 : 0, nullptr, 0, 1, 0, wshift);
+    c.q2 = make_qp_args(h, h->alive, &o, 1, nullptr, 1, 1, 1, wshift);
+    EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff, h->stale, 1};
+    ConvArgs ca{B, h->n, h->primal, h->prev_primal, h->has_prev, h->alive, h->conv, o.conv_tol};
+    c.aq = AfterQpArgs{B, 1, 1, h->status, active, h->alive, h->infeas, h->mask, h->success, h->itnum, h->counter, h->stale, h->conv, ea, ca, h->beta, h->beta_f};
+    SweepArgs sa;
+    sa.B = h->B; sa.N = d.N; sa.NW = d.nw; sa.A = h->A; sa.Bm = h->Bm; sa.E = h->E; sa.E_per_instance = 0; sa.eta = h->eta; sa.eta_f = h->eta_f;
+    sa.run = h->mask; sa.cst = costs_of(h); sa.K = h->K; sa.beta = h->beta; sa.beta_f = h->beta_f; sa.ct_part = h->ct_part; sa.eps = o.eps_backoff;
+    c.sw = SweepSharedArgs{sa, h->Kc, h->Aclc, h->stale};
+    c.ta = TightenArgs{B, d.N, d.nx, d.nu, d.ni, d.ni_f, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1, h->ct_part, h->cost_tube};
+    c.active = active; c.success = h->success; c.infeas = h->infeas; c.times = h->chain_times;
+    c.max_ticks = qp_max_ticks(c.q1, o.qp_max_iter);
+    c.lag = nullptr; c.runm = nullptr; c.done = nullptr; c.t0word = nullptr; c.budget = 0; c.qplog = nullptr; c.stepno = nullptr; c.log_steps = 0; c.fin_count = nullptr; c.cut_count = 0xFFFFFFFFu;
+    return c;
 }
 
 // the fused RTI chain (k_rti_chain): one launch for QP #1 -> eta -> shared Riccati + propagation -> tightened bounds -> QP #2
@@ -912,20 +1108,7 @@ static int solve_impl(slsqp_handle *h, const double *x0, int loc, const slsqp_op
     if (rti && steps == 1 && o.precision == 0 && fuse_here && chain_allowed() && sweep_shared_allowed() && !h->general_G) {
         // fast_SLS.solve with rti_steps = 1 (the rocket script's setting) as ONE launch: every wave takes its instance through the whole chain
         h->time_kernels = o.time_kernels != 0;
-        ChainArgs c;
-        c.q1 = make_qp_args(h, h->alive, &o, o.warm_start ? 1 : 0, nullptr, 0, 1, 0, wshift);
-        c.q2 = make_qp_args(h, h->alive, &o, 1, nullptr, 1, 1, 1, wshift);
-        EtaArgs ea{B, d.N, d.nx, d.ni, d.ni_f, h->dual, h->beta, h->beta_f, h->alive, h->eta, h->eta_f, o.eps_backoff, h->stale, 1};
-        ConvArgs ca{B, h->n, h->primal, h->prev_primal, h->has_prev, h->alive, h->conv, o.conv_tol};
-        c.aq = AfterQpArgs{B, 1, 1, h->status, active, h->alive, h->infeas, h->mask, h->success, h->itnum, h->counter, h->stale, h->conv, ea, ca, h->beta, h->beta_f};
-        SweepArgs sa;
-        sa.B = h->B; sa.N = d.N; sa.NW = d.nw; sa.A = h->A; sa.Bm = h->Bm; sa.E = h->E; sa.E_per_instance = 0; sa.eta = h->eta; sa.eta_f = h->eta_f;
-        sa.run = h->mask; sa.cst = costs_of(h); sa.K = h->K; sa.beta = h->beta; sa.beta_f = h->beta_f; sa.ct_part = h->ct_part; sa.eps = o.eps_backoff;
-        c.sw = SweepSharedArgs{sa, h->Kc, h->Aclc, h->stale};
-        c.ta = TightenArgs{B, d.N, d.nx, d.nu, d.ni, d.ni_f, h->beta, h->beta_f, h->g, h->gf_raw, h->c, h->mask, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, h->ubg, 1, h->ct_part, h->cost_tube};
-        c.active = active; c.success = h->success; c.infeas = h->infeas; c.times = h->chain_times;
-        c.max_ticks = qp_max_ticks(c.q1, o.qp_max_iter);
-        c.lag = nullptr; c.runm = nullptr; c.done = nullptr; c.t0word = nullptr; c.budget = 0; c.qplog = nullptr; c.stepno = nullptr; c.log_steps = 0; c.fin_count = nullptr; c.cut_count = 0xFFFFFFFFu;
+        ChainArgs c = make_chain_args(h, o, active, wshift);
         if (h->cl_round) {      // a round of slsqp_cl_run: suspended solves resume, unfinished ones suspend at the deadline
             c.lag = h->cl_lag; c.runm = h->cl_runm; c.done = h->cl_done; c.t0word = h->t0word; c.budget = h->cl_budget;
             c.qplog = h->qplog; c.stepno = h->cl_stepno; c.log_steps = h->qplog_steps;
@@ -1091,7 +1274,7 @@ static int linearize_impl(slsqp_handle *h, const double *X, const double *U, int
         HIPCHK(hipMemcpyAsync(tmp + nX, U, sizeof(double) * nU, hipMemcpyHostToDevice, h->st));
         dX = tmp; dU = tmp + nX;
     }
-    LinArgs a{h->B, d.N, dX, dU, h->g_raw, h->gf_raw, costs_of(h), h->A, h->Bm, h->c, h->g, h->gN, h->q, run, h->lin_stage};
+    LinArgs a{h->B, d.N, dX, dU, h->g_raw, h->gf_raw, costs_of(h), h->A, h->Bm, h->c, h->g, h->gN, h->q, run, h->lin_stage, h->lin_tape};
     const int grid = 2048, blk = 128;
     const int gval = (int)((B * d.N + blk - 1) / blk);
     if (h->model_id == 0) {
@@ -1304,6 +1487,93 @@ __global__ void k_cl_begin_flags(int B, const int *begin, int *scp_success, int 
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B && begin[b]) { scp_success[b] = 0; scp_iters[b] = 0; }
 }
+// the persistent closed-loop launch (k_cl_loop): as many waves as the GPU holds at the kernel's occupancy (or as there are instances)
+template <int MODEL>
+static int launch_loop_t(slsqp_handle *h, LoopArgs &L) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
+    const size_t lds = sizeof(double) * std::max({(size_t)qp_lds_doubles<NX, NU>(h->d.N), (size_t)(2 * h->n + 8), (size_t)sweep_lds_doubles<NX, NU>(), (size_t)sweep_prop_lds_doubles<NX, NU>()});
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->dev) != hipSuccess || cu <= 0) cu = 256;
+    const int env_waves = getenv("SLSQP_LOOP_WAVES") ? atoi(getenv("SLSQP_LOOP_WAVES")) : 0;      // (tests / experiments: fewer waves than the GPU holds)
+    const int slots = env_waves > 0 ? env_waves : cu * 4 * QP_PERSIST_WAVES_PER_SIMD;
+    const int grid = std::max(1, std::min(h->B, slots));
+    h->cl_loop_waves = grid;
+    const bool timed = h->time_kernels && h->n_kev + 2 <= (int)h->kev.size();
+    if (timed) hipEventRecord(h->kev[h->n_kev], h->st);
+    hipEventRecord(h->ev[8], h->st);
+    hipLaunchKernelGGL((k_cl_loop<MODEL>), dim3(grid), dim3(64), lds, h->st, L);
+    hipEventRecord(h->ev[9], h->st);
+    if (timed) { hipEventRecord(h->kev[h->n_kev + 1], h->st); h->n_kev += 2; }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int cl_run_persistent(slsqp_handle *h, int steps, const double *dW, const slsqp_opts &o, int *rounds_out) {
+    const slsqp_dims &d = h->d;
+    const int B = h->B;
+    if (!h->beta_inited) {      // what the handle's first solve does once: beta = eps everywhere (later solves only repair swept instances)
+        hipLaunchKernelGGL(k_fill_doubles, dim3(1024), dim3(256), 0, h->st, h->beta, o.eps_backoff, (size_t)B * d.N * d.N * d.ni);
+        hipLaunchKernelGGL(k_fill_doubles, dim3(1024), dim3(256), 0, h->st, h->beta_f, o.eps_backoff, (size_t)B * (d.N + 1) * d.ni_f);
+        h->beta_inited = true;
+    }
+    h->time_kernels = o.time_kernels != 0;
+    LoopArgs L;
+    L.c = make_chain_args(h, o, nullptr, 1);
+    L.c.q1.call_ids = L.c.q2.call_ids = h->call_ids;
+    L.c.q1.shift_stepno = L.c.q2.shift_stepno = h->cl_stepno;      // the horizon has moved for the instances past their first step
+    L.c.qplog = h->qplog; L.c.stepno = h->cl_stepno; L.c.log_steps = h->qplog_steps;
+    L.cl = cl_args(h, nullptr);
+    L.lin = LinArgs{B, d.N, h->Xn, h->Un, h->g_raw, h->gf_raw, costs_of(h), h->A, h->Bm, h->c, h->g, h->gN, h->q, nullptr, h->lin_stage, h->lin_tape};
+    L.ba = BoundsArgs{B, d.N, d.nx, d.ni, d.ni_f, h->g, h->gN, h->c, h->ubg, h->lbg, 1e-10, nullptr};
+    L.sb = SolveBeginArgs{B, d.nx, h->x0arg, h->x0val, nullptr, h->alive, h->infeas, h->success, h->pending_reset, h->itnum, h->stale,
+                          h->eta, h->eta_f, (size_t)d.N * d.N * d.ni, (size_t)(d.N + 1) * d.ni_f,
+                          InitBackoffArgs{B, d.N, d.nx, d.nu, o.eps_backoff, nullptr, h->beta, h->beta_f, h->backoff, h->backoff_f, h->backoff_x, h->backoff_u, 0}, nullptr};
+    L.lg = ClLogArgs{h->cl_stepno, nullptr, B, d.N, d.nx, d.nu, h->log_steps, 0, h->Xn, h->Un, h->backoff_x, h->backoff_u, h->scp_success, h->scp_iters,
+                     h->pinf, h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_pinf, h->lg_succ, h->lg_it};
+    L.sa = ScpArgs{0, 0, o.scp_eps, h->scp_active, h->scp_success, h->scp_iters, h->counter + 2, h->scp_dmax, h->scp_upd};
+    L.steps = steps; L.n = h->n; L.have_log = h->log_steps > 0 ? 1 : 0;
+    L.fence = getenv("SLSQP_LOOP_FENCE") ? atoi(getenv("SLSQP_LOOP_FENCE")) : 3;      // (experiments only: 0 drops the hand-over fences)
+    L.stepno = h->cl_stepno; L.call_ids = h->call_ids; L.q = h->q; L.stale = h->stale; L.itnum = h->itnum; L.pending = h->pending_reset; L.scp_active = h->scp_active;
+    L.W_all = dW; L.pinf = h->pinf;
+    L.Q = ClQueue{h->clq_slots, h->clq_cap - 1u, (unsigned *)h->clq_ctl, (unsigned *)h->clq_ctl + 1, h->clq_ctl + 2, h->clq_ctl + 3};
+    L.busy = h->cl_busy; L.t_begin = h->cl_tbegin;
+    hipLaunchKernelGGL(k_clq_init, dim3(64), dim3(256), 0, h->st, B, L.Q);
+    HIPCHK(hipMemsetAsync(h->cl_busy, 0, 16 * sizeof(unsigned long long), h->st));
+    HIPCHK(hipMemsetAsync(h->counter + 2, 0, sizeof(int), h->st));
+    const int tl_tot = tl_begin(h, 2), tl_c = tl_begin(h, 4);
+    int rc = -1;
+    if (h->model_id == 0) rc = launch_loop_t<0>(h, L);
+    else if (h->model_id == 1) rc = launch_loop_t<1>(h, L);
+    else rc = launch_loop_t<2>(h, L);
+    if (rc) return -1;
+    tl_end(h, tl_c); tl_end(h, tl_tot);
+    int ctl[4] = {0, 0, 0, 0};
+    std::vector<int> sn((size_t)B);
+    HIPCHK(hipMemcpyAsync(ctl, h->clq_ctl, sizeof(ctl), hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipMemcpyAsync(sn.data(), h->cl_stepno, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipMemcpyAsync(h->cl_busy_host, h->cl_busy, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->st));
+    if (h->chain_times_host) HIPCHK(hipMemcpyAsync(h->chain_times_host, h->chain_times, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->st));
+    HIPCHK(hipStreamSynchronize(h->st));
+    tl_take(h);
+    h->cl_loop_ms = ev_ms(h->ev[8], h->ev[9]);
+    h->have_dyn = true;
+    int unfinished = 0;
+    for (int b = 0; b < B; b++) unfinished += sn[b] < steps ? 1 : 0;
+    if (ctl[3] != 0 || unfinished != 0)
+        return fail("slsqp_cl_run (persistent): the instance queue did not drain (err " + std::to_string(ctl[3]) + ", " + std::to_string(unfinished) + " instances short of their steps)");
+    h->cl_steps = steps;
+    h->call_id += steps;
+    if (rounds_out) *rounds_out = 1;
+    return 0;
+}
+// wave statistics of the last persistent slsqp_cl_run: [0] waves launched, [1] sum over the MPC steps of the time a wave spent on them (ms),
+// [2] MPC steps run, [3] duration of the launch (ms; HIP events, opts.time_kernels)
+extern "C" int slsqp_cl_run_stats(slsqp_handle *h, double *out, int len) {
+    if (!out || len < SLSQP_CL_RUN_STATS_LEN) return fail("slsqp_cl_run_stats: the buffer must hold SLSQP_CL_RUN_STATS_LEN (4) doubles");
+    out[0] = (double)h->cl_loop_waves; out[1] = (double)h->cl_busy_host[0] * 1e-5; out[2] = (double)h->cl_busy_host[2]; out[3] = h->cl_loop_ms;
+    for (int i = 4; i < 16 && i < len; i++) out[i] = (double)h->cl_busy_host[i] * 1e-5;      // -DCL_LOOP_STAMP builds: ms spent in the parts of the step around the chain
+    return 0;
+}
+
 // `steps` MPC steps of every instance (rti = 1 with one fast-SLS step: the rocket script's setting), W (steps, B, nx) or NULL.  Per instance the
 // same sequence of operations as `steps` calls of slsqp_cl_step -- same bits -- but no instance waits for another: the loop runs in ROUNDS (one
 // burst of launches each); in a round an instance either begins its next MPC step (shift, reset, linearise, chain, nominal update, plant) or
@@ -1344,6 +1614,7 @@ extern "C" int slsqp_cl_run(slsqp_handle *h, int steps, const double *W, int loc
     HIPCHK(hipMemsetAsync(h->cl_stepno, 0, sizeof(int) * B, h->st));
     HIPCHK(hipMemsetAsync(h->cl_lag, 0, sizeof(int) * B, h->st));
     hipLaunchKernelGGL(k_fill_doubles, dim3(64), dim3(256), 0, h->st, h->call_ids, h->call_id, (size_t)B);
+    if (o.cl_persistent) return cl_run_persistent(h, steps, dW, o, rounds_out);
     h->cl_budget = budget_ms > 0.0 ? (unsigned long long)(std::max(0.05, budget_ms) * 1e5) : (1ULL << 62);
     h->cl_total_steps = steps;
     ClArgs a = cl_args(h, nullptr);

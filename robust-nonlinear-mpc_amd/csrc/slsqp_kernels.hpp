@@ -93,6 +93,7 @@ struct QpArgs {
     int as_first;             // 1: a cold solve first tries the active-set iteration from the empty set (the equality-constrained optimum of P_INIT)
     int as_rounds;            // rounds such an attempt may take (a warm one: warm_rounds)
     int *diag;                // QP_DIAG_SPAN builds: (B,2,16,2) first / last stage whose set entry changed, per active-set round
+    const int *shift_stepno;  // NULL, or (B): warm_shift applies to the instances with shift_stepno[b] > 0 only (k_cl_loop: every instance is at its own MPC step)
     int warm_shift;           // 1: the first QP's warm set is the previous call's set moved one stage towards the start of the horizon (receding horizon)
     int as_warm_max_set;      // a QP that follows another one of the same call (tightened bounds) skips the warm attempt and goes straight to the
                               // interior point when the set it would start from has more entries than this (0 = never): from ~30 active bounds a
@@ -536,6 +537,9 @@ struct QpState {   // per instance, 40 doubles
 };
 static_assert(sizeof(QpState) == 40 * sizeof(double), "QpState size");
 
+#ifndef LAUNDER_B
+#define LAUNDER_B(b) asm volatile("" : "+s"(b))
+#endif
 template <int NX, int NU>
 __device__ __forceinline__ NeG<NX, NU> make_neg(const QpArgs &a, int b) {
     using L = Lay<NX, NU>;
@@ -615,7 +619,7 @@ __device__ __forceinline__ void phase_update(const QpArgs &a, int first, int b, 
         // 5-20 % of the steps; their successors were most of the warm attempts that failed)
         int okbits = (int)stp->act1_ok;
         int age1 = (okbits >> 2) & 255, age2 = (okbits >> 10) & 255;
-        if (a.stat_slot == 0 && a.snap_use == 0 && a.warm_shift) { age1 = min(age1 + 1, 255); age2 = min(age2 + 1, 255); }      // the call's first QP sees the shift once
+        if (a.stat_slot == 0 && a.snap_use == 0 && a.warm_shift && (!a.shift_stepno || a.shift_stepno[b] > 0)) { age1 = min(age1 + 1, 255); age2 = min(age2 + 1, 255); }      // the call's first QP sees the shift once
         okbits = (okbits & 3) | (age1 << 2) | (age2 << 10);
         const bool from_act1 = a.warm && status == ST_INIT && a.stat_slot == 0 && a.snap_use == 0 && (okbits & 1);
         bool warm = a.warm && status == ST_INIT && (from_act1 || (((int)stp->status == 0) && ((int)stp->phase == P_DONE)));
@@ -1290,7 +1294,7 @@ __device__ __forceinline__ int qp_solve_dev(const QpArgs &a, int b, int lane, do
         // The instance index and the lane id are laundered through empty asm statements at the head of every part: nothing computed from them
         // is loop-invariant for the compiler then, so it cannot hoist the phase logic's per-element loads (bounds, weights, linear cost) out of
         // the tick loop and keep them in registers across the sweeps (256 VGPRs + 118 spilled when it does; 168-194 like this).
-        asm volatile("" : "+s"(b));
+        LAUNDER_B(b);
         asm volatile("" : "+v"(lane));
         QpState *st = (QpState *)a.state + b;
         const int phase = (int)st->phase;
@@ -1320,7 +1324,7 @@ __device__ __forceinline__ int qp_solve_dev(const QpArgs &a, int b, int lane, do
 #ifdef QP_STAMP
         if (factor) QSTAMP(c_fwdf); else QSTAMP(c_fwd);
 #endif
-        asm volatile("" : "+s"(b));
+        LAUNDER_B(b);
         asm volatile("" : "+v"(lane));
         if (!res_only_done) {
             if constexpr (MX) ne_backward_mx<NX, NU>(sm, make_neg<NX, NU>(a, b), lane);
@@ -1328,7 +1332,7 @@ __device__ __forceinline__ int qp_solve_dev(const QpArgs &a, int b, int lane, do
         }
         wla::wsync_mem();
         QSTAMP(c_bwd);
-        asm volatile("" : "+s"(b));
+        LAUNDER_B(b);
         asm volatile("" : "+v"(lane));
         phase_update<NX, NU>(a, 0, b, lane, sm);
         wla::wsync_mem();
@@ -1353,19 +1357,23 @@ __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_qp_solve(QpAr
 // bounds of the un-tightened QP: QP.update_dynamics (qp_jit.py:268-273) + offset_constraints (:595-610)
 // ------------------------------------------------------------------------------------------------
 struct BoundsArgs { int B, N, NX, NI, NIF; const double *g, *gN, *c; double *ubg, *lbg; double eps; const int *run; };
+__device__ __forceinline__ void set_bounds_row(const BoundsArgs &a, int b, int r) {
+    const int SR = a.NX + a.NI, mb = a.N * SR + a.NIF;
+    double u, l;
+    if (r < a.N * SR) {
+        const int k = r / SR, i = r % SR;
+        if (i < a.NX) { const double cv = a.c[((size_t)b * a.N + k) * a.NX + i]; u = -cv + a.eps; l = -cv - a.eps; }
+        else { u = a.g[((size_t)b * a.N + k) * a.NI + (i - a.NX)] + a.eps; l = -1e20; }
+    } else { u = a.gN[(size_t)b * a.NIF + (r - a.N * SR)] + a.eps; l = -1e20; }
+    a.ubg[(size_t)b * mb + r] = u; a.lbg[(size_t)b * mb + r] = l;
+}
 __global__ void k_set_bounds(BoundsArgs a) {
     const int SR = a.NX + a.NI, mb = a.N * SR + a.NIF;
     const size_t tot = (size_t)a.B * mb;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
         const int b = idx / mb, r = idx % mb;
         if (a.run && !a.run[b]) continue;
-        double u, l;
-        if (r < a.N * SR) {
-            const int k = r / SR, i = r % SR;
-            if (i < a.NX) { const double cv = a.c[((size_t)b * a.N + k) * a.NX + i]; u = -cv + a.eps; l = -cv - a.eps; }
-            else { u = a.g[((size_t)b * a.N + k) * a.NI + (i - a.NX)] + a.eps; l = -1e20; }
-        } else { u = a.gN[(size_t)b * a.NIF + (r - a.N * SR)] + a.eps; l = -1e20; }
-        a.ubg[idx] = u; a.lbg[idx] = l;
+        set_bounds_row(a, b, r);
     }
 }
 
@@ -2132,26 +2140,45 @@ struct LinArgs {
     double *A, *Bm, *c, *g, *gN, *q;
     const int *run;   // (B) 1 = linearise this instance (NULL = all)
     double *stage;    // scratch (B,N,3,NX): intermediate RK4 stage points of every (instance, stage), k_lin_val -> k_lin_tan
+    double *tape;     // scratch (B,N,4,NT_MAX): the transcendental values of the four ODE evaluations of every (instance, stage) (dyn::MathRecord -> MathReplay)
 };
+#ifndef CLW_FN
+#define CLW_FN __forceinline__      // the per-step glue of k_cl_loop (as functions called through the ABI the QP loops' allocation gets worse: 608 against 323 scratch loads)
+#endif
 // linearisation in two kernels: values (one thread per (instance, stage): RK4 step, its three intermediate points, the defect c_k) ...
 template <int MODEL>
-__global__ __launch_bounds__(128) void k_lin_val(LinArgs a) {
+__device__ __forceinline__ void lin_val_item(const LinArgs &a, int b, int k) {
     constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
+    const size_t t = (size_t)b * a.N + k;
+    const double *xg = a.X + ((size_t)b * (a.N + 1) + k) * NX, *ug = a.U + ((size_t)b * a.N + k) * NU;
+    double x[NX], u[NU], st[3 * NX], f[NX];
+    for (int i = 0; i < NX; i++) x[i] = xg[i];
+    for (int i = 0; i < NU; i++) u[i] = ug[i];
+    dyn::ddyn_stages<MODEL>(x, u, st, f, a.tape + t * 4 * dyn::NT_MAX);
+    double *sg = a.stage + t * 3 * NX, *c = a.c + t * NX;
+    for (int i = 0; i < 3 * NX; i++) sg[i] = st[i];
+    for (int i = 0; i < NX; i++) c[i] = f[i] - xg[NX + i];
+}
+template <int MODEL>
+__global__ __launch_bounds__(128) void k_lin_val(LinArgs a) {
     const size_t tot = (size_t)a.B * a.N;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
         const int k = t % a.N, b = t / a.N;
         if (a.run && !a.run[b]) continue;
-        const double *xg = a.X + ((size_t)b * (a.N + 1) + k) * NX, *ug = a.U + ((size_t)b * a.N + k) * NU;
-        double x[NX], u[NU], st[3 * NX], f[NX];
-        for (int i = 0; i < NX; i++) x[i] = xg[i];
-        for (int i = 0; i < NU; i++) u[i] = ug[i];
-        dyn::ddyn_stages<MODEL>(x, u, st, f);
-        double *sg = a.stage + t * 3 * NX, *c = a.c + t * NX;
-        for (int i = 0; i < 3 * NX; i++) sg[i] = st[i];
-        for (int i = 0; i < NX; i++) c[i] = f[i] - xg[NX + i];
+        lin_val_item<MODEL>(a, b, k);
     }
 }
 // ... and tangents (one thread per (instance, stage, direction): forward-mode AD through the four ODE evaluations, stage values read back)
+template <int MODEL>
+__device__ __forceinline__ void lin_tan_item(const LinArgs &a, int b, int k, int dir) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
+    const size_t bk = (size_t)b * a.N + k;
+    const double *x = a.X + ((size_t)b * (a.N + 1) + k) * NX, *u = a.U + bk * NU;
+    double col[NX];
+    dyn::ddyn_tangent<MODEL>(x, u, a.stage + bk * 3 * NX, a.tape + bk * 4 * dyn::NT_MAX, dir, col);
+    if (dir < NX) { double *A = a.A + bk * NX * NX; for (int i = 0; i < NX; i++) A[i * NX + dir] = col[i]; }
+    else { double *Bm = a.Bm + bk * NX * NU; for (int i = 0; i < NX; i++) Bm[i * NU + (dir - NX)] = col[i]; }
+}
 template <int MODEL>
 __global__ __launch_bounds__(128) void k_lin_tan(LinArgs a) {
     constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU, NZ = NX + NU;
@@ -2159,33 +2186,48 @@ __global__ __launch_bounds__(128) void k_lin_tan(LinArgs a) {
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
         const int dir = t % NZ, k = (t / NZ) % a.N, b = t / ((size_t)NZ * a.N);
         if (a.run && !a.run[b]) continue;
-        const size_t bk = (size_t)b * a.N + k;
-        const double *x = a.X + ((size_t)b * (a.N + 1) + k) * NX, *u = a.U + bk * NU;
-        double col[NX];
-        dyn::ddyn_tangent<MODEL>(x, u, a.stage + bk * 3 * NX, dir, col);
-        if (dir < NX) { double *A = a.A + bk * NX * NX; for (int i = 0; i < NX; i++) A[i * NX + dir] = col[i]; }
-        else { double *Bm = a.Bm + bk * NX * NU; for (int i = 0; i < NX; i++) Bm[i * NU + (dir - NX)] = col[i]; }
+        lin_tan_item<MODEL>(a, b, k, dir);
+    }
+}
+template <int NX, int NU>
+__device__ __forceinline__ void lin_vec_item(const LinArgs &a, int b, int e) {
+    constexpr int NZ = NX + NU, NI = 2 * NZ, NIF = 2 * NX;
+    const int n = NZ * a.N + NX, k = e / NZ, i = e % NZ;
+    const double z = (i < NX) ? a.X[((size_t)b * (a.N + 1) + k) * NX + i] : a.U[((size_t)b * a.N + k) * NU + (i - NX)];
+    if (k < a.N) {
+        double *g = a.g + ((size_t)b * a.N + k) * NI;
+        g[i] = a.g_raw[i] - z; g[NZ + i] = a.g_raw[NZ + i] + z;
+        a.q[(size_t)b * n + e] = 2.0 * (i < NX ? a.cst.Qd[i] : a.cst.Rd[i - NX]) * z;
+    } else {
+        double *g = a.gN + (size_t)b * NIF;
+        g[i] = a.gf_raw[i] - z; g[NX + i] = a.gf_raw[NX + i] + z;
+        a.q[(size_t)b * n + e] = 2.0 * a.cst.Qfd[i] * z;
     }
 }
 template <int NX, int NU>
 __global__ void k_lin_vec(LinArgs a) {
-    constexpr int NZ = NX + NU, NI = 2 * NZ, NIF = 2 * NX;
+    constexpr int NZ = NX + NU;
     const int n = NZ * a.N + NX;
     const size_t tot = (size_t)a.B * n;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
-        const int e = t % n, b = t / n, k = e / NZ, i = e % NZ;
+        const int e = t % n, b = t / n;
         if (a.run && !a.run[b]) continue;
-        const double z = (i < NX) ? a.X[((size_t)b * (a.N + 1) + k) * NX + i] : a.U[((size_t)b * a.N + k) * NU + (i - NX)];
-        if (k < a.N) {
-            double *g = a.g + ((size_t)b * a.N + k) * NI;
-            g[i] = a.g_raw[i] - z; g[NZ + i] = a.g_raw[NZ + i] + z;
-            a.q[t] = 2.0 * (i < NX ? a.cst.Qd[i] : a.cst.Rd[i - NX]) * z;
-        } else {
-            double *g = a.gN + (size_t)b * NIF;
-            g[i] = a.gf_raw[i] - z; g[NX + i] = a.gf_raw[NX + i] + z;
-            a.q[t] = 2.0 * a.cst.Qfd[i] * z;
-        }
+        lin_vec_item<NX, NU>(a, b, e);
     }
+}
+// the whole linearisation of ONE instance by one wave (the persistent closed-loop kernel k_cl_loop): same items, same arithmetic
+template <int MODEL>
+__device__ CLW_FN void lin_wave(const LinArgs &a, const BoundsArgs &ba, int b, int lane) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU, NZ = NX + NU;
+    const int n = NZ * a.N + NX;
+    if (lane < a.N) lin_val_item<MODEL>(a, b, lane);
+    wla::wsync_mem();
+    for (int t = lane; t < a.N * NZ; t += 64) lin_tan_item<MODEL>(a, b, t / NZ, t % NZ);
+    for (int e = lane; e < n; e += 64) lin_vec_item<NX, NU>(a, b, e);
+    wla::wsync_mem();
+    const int mb = ba.N * (ba.NX + ba.NI) + ba.NIF;
+    for (int r = lane; r < mb; r += 64) set_bounds_row(ba, b, r);
+    wla::wsync_mem();
 }
 
 
@@ -2210,9 +2252,7 @@ struct ClArgs {
 //   RTI mode                         -> scp_success = success of the last step                             (:148)
 // One wave per instance; n_active counts the instances that go on.
 struct ScpArgs { int ii, converge; double eps; int *active, *scp_success, *scp_iters, *n_active; double *dmax; int *updated; };
-__global__ __launch_bounds__(64) void k_cl_scp_update(ClArgs a, ScpArgs s) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B) return;
+__device__ __forceinline__ void cl_scp_update_wave(const ClArgs &a, const ScpArgs &s, int b, int lane) {
     if (!s.active[b]) { if (lane == 0) s.updated[b] = 0; return; }
     const int NZ = a.NX + a.NU, n = NZ * a.N + a.NX;
     if (!a.success[b]) {
@@ -2239,6 +2279,11 @@ __global__ __launch_bounds__(64) void k_cl_scp_update(ClArgs a, ScpArgs s) {
         } else { s.scp_success[b] = 1; atomicAdd(s.n_active, 1); }
     }
 }
+__global__ __launch_bounds__(64) void k_cl_scp_update(ClArgs a, ScpArgs s) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B) return;
+    cl_scp_update_wave(a, s, b, lane);
+}
 __global__ void k_cl_x0arg(ClArgs a, const int *mask = nullptr) {
     const int tot = a.B * a.NX;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += gridDim.x * blockDim.x) {
@@ -2250,10 +2295,8 @@ __global__ void k_cl_x0arg(ClArgs a, const int *mask = nullptr) {
 // primal_infeasibility of SCP_SLS.socp_step (solver/SCP_SLS_jit.py:449-456): the signed maximum over stages and components of
 // ddyn(x_k,u_k) - x_{k+1} along the nominal just updated.  One wave per instance, lane k = stage k (N <= 64).
 template <int MODEL>
-__global__ __launch_bounds__(64) void k_cl_infeas(ClArgs a, const int *updated, double *pinf) {
+__device__ __forceinline__ void cl_infeas_wave(const ClArgs &a, double *pinf, int b, int k) {
     constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
-    const int b = blockIdx.x, k = threadIdx.x;
-    if (b >= a.B || !updated[b]) return;
     const double *X = a.Xn + (size_t)b * (a.N + 1) * NX, *U = a.Un + (size_t)b * a.N * NU;
     double mx = -1e300;
     if (k < a.N) {
@@ -2266,6 +2309,12 @@ __global__ __launch_bounds__(64) void k_cl_infeas(ClArgs a, const int *updated, 
     mx = wla::wave_max(mx);
     if (k == 0) pinf[b] = mx;
 }
+template <int MODEL>
+__global__ __launch_bounds__(64) void k_cl_infeas(ClArgs a, const int *updated, double *pinf) {
+    const int b = blockIdx.x, k = threadIdx.x;
+    if (b >= a.B || !updated[b]) return;
+    cl_infeas_wave<MODEL>(a, pinf, b, k);
+}
 // device-side log of a closed-loop run (what the scripts store per MPC step, expe/main_rocket_robust_closed_loop.py:160-178): entry `step`
 // of (B, S, ...) buffers, so a whole Monte-Carlo run needs no host round trip per step
 struct ClLogArgs {
@@ -2277,31 +2326,59 @@ struct ClLogArgs {
     double *lx, *lu, *lbx, *lbu, *lstate, *lu0, *lpinf;
     int *lsucc, *lit;
 };
+__device__ __forceinline__ void cl_log_item(const ClLogArgs &a, int b, int o0) {
+    const int nX = (a.N + 1) * a.NX, nU = a.N * a.NU;
+    int o = o0;
+    const size_t e = (size_t)b * a.S + (a.stepno ? min(a.stepno[b], a.S - 1) : a.step);
+    if (o < nX) {
+        const double v = a.Xn[(size_t)b * nX + o];
+        a.lx[e * nX + o] = v;
+        if (o < a.NX) a.lstate[e * a.NX + o] = v;
+    } else if ((o -= nX) < nU) {
+        const double v = a.Un[(size_t)b * nU + o];
+        a.lu[e * nU + o] = v;
+        if (o < a.NU) a.lu0[e * a.NU + o] = v;
+    } else if ((o -= nU) < nX) a.lbx[e * nX + o] = a.bx[(size_t)b * nX + o];
+    else { o -= nX; a.lbu[e * nU + o] = a.bu[(size_t)b * nU + o]; }
+    if (o0 == 0) { a.lsucc[e] = a.success[b]; a.lit[e] = a.scp_iters[b]; a.lpinf[e] = a.pinf[b]; }
+}
 __global__ void k_cl_log(ClLogArgs a) {
     const int nX = (a.N + 1) * a.NX, nU = a.N * a.NU, per = 2 * nX + 2 * nU;
     const size_t tot = (size_t)a.B * per;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
         const int b = t / per;
-        int o = t % per;
         if (a.mask && !a.mask[b]) continue;
-        const size_t e = (size_t)b * a.S + (a.stepno ? min(a.stepno[b], a.S - 1) : a.step);
-        if (o < nX) {
-            const double v = a.Xn[(size_t)b * nX + o];
-            a.lx[e * nX + o] = v;
-            if (o < a.NX) a.lstate[e * a.NX + o] = v;
-        } else if ((o -= nX) < nU) {
-            const double v = a.Un[(size_t)b * nU + o];
-            a.lu[e * nU + o] = v;
-            if (o < a.NU) a.lu0[e * a.NU + o] = v;
-        } else if ((o -= nU) < nX) a.lbx[e * nX + o] = a.bx[(size_t)b * nX + o];
-        else { o -= nX; a.lbu[e * nU + o] = a.bu[(size_t)b * nU + o]; }
-        if (t % per == 0) { a.lsucc[e] = a.success[b]; a.lit[e] = a.scp_iters[b]; a.lpinf[e] = a.pinf[b]; }
+        cl_log_item(a, b, (int)(t % per));
     }
 }
 // warm-start shift (SCP_SLS_jit.py:508-518): x_k <- x_{k+1}, u_k <- u_{k+1}, u_{N-1} kept, x_N <- ddyn(x_N, u_{N-1});
 // plant step (expe/main_rocket...:180-182): x_meas <- ddyn(x_meas, u0) + E w.   One thread per instance.
 // slsqp_cl_run: mask (B) selects the instances; shift only those past their first step (stepno > 0); the disturbance sample of an instance is the one
 // of ITS step, W_all (steps, B, NX).
+template <int MODEL>
+__device__ __forceinline__ void cl_plant_one(const ClArgs &a, int b, const double *w /* (B,NX) sample or NULL */) {      // one thread
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
+    const double *U = a.Un + (size_t)b * a.N * NU;
+    double xm[NX], u[NU], xp[NX];
+    for (int i = 0; i < NX; i++) xm[i] = a.xmeas[(size_t)b * NX + i];
+    for (int i = 0; i < NU; i++) { u[i] = U[i]; a.u0[(size_t)b * NU + i] = u[i]; }
+    dyn::ddyn<MODEL, double>(xm, u, xp);
+    for (int i = 0; i < NX; i++) {
+        double s = xp[i];
+        if (w) for (int j = 0; j < NX; j++) s += a.E[i * NX + j] * w[(size_t)b * NX + j];
+        a.xmeas[(size_t)b * NX + i] = s;
+    }
+}
+// the new last state of the shifted nominal: ddyn(x_N, u_{N-1}) of the nominal BEFORE the shift (one thread)
+template <int MODEL>
+__device__ __forceinline__ void cl_shift_tail(const ClArgs &a, int b, double *xp) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
+    const double *X = a.Xn + (size_t)b * (a.N + 1) * NX, *U = a.Un + (size_t)b * a.N * NU;
+    double xN[NX], uN[NU];
+    for (int i = 0; i < NX; i++) xN[i] = X[(size_t)a.N * NX + i];
+    for (int i = 0; i < NU; i++) uN[i] = U[(size_t)(a.N - 1) * NU + i];
+    dyn::ddyn<MODEL, double>(xN, uN, xp);
+}
 template <int MODEL>
 __global__ void k_cl_shift_plant(ClArgs a, int do_shift, int do_plant, const int *mask = nullptr, const int *stepno = nullptr, const double *W_all = nullptr) {
     constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
@@ -2311,26 +2388,35 @@ __global__ void k_cl_shift_plant(ClArgs a, int do_shift, int do_plant, const int
     if (do_shift && stepno && stepno[b] == 0) return;
     if (W_all) a.w = W_all + (size_t)stepno[b] * a.B * NX;      // (mask[b] implies stepno[b] < steps: only instances whose chain ended in this round)
     double *X = a.Xn + (size_t)b * (a.N + 1) * NX, *U = a.Un + (size_t)b * a.N * NU;
-    if (do_plant) {
-        double xm[NX], u[NU], xp[NX];
-        for (int i = 0; i < NX; i++) xm[i] = a.xmeas[(size_t)b * NX + i];
-        for (int i = 0; i < NU; i++) { u[i] = U[i]; a.u0[(size_t)b * NU + i] = u[i]; }
-        dyn::ddyn<MODEL, double>(xm, u, xp);
-        for (int i = 0; i < NX; i++) {
-            double s = xp[i];
-            if (a.w) for (int j = 0; j < NX; j++) s += a.E[i * NX + j] * a.w[(size_t)b * NX + j];
-            a.xmeas[(size_t)b * NX + i] = s;
-        }
-    }
+    if (do_plant) cl_plant_one<MODEL>(a, b, a.w);
     if (do_shift) {
-        double xN[NX], uN[NU], xp[NX];
-        for (int i = 0; i < NX; i++) xN[i] = X[(size_t)a.N * NX + i];
-        for (int i = 0; i < NU; i++) uN[i] = U[(size_t)(a.N - 1) * NU + i];
-        dyn::ddyn<MODEL, double>(xN, uN, xp);
+        double xp[NX];
+        cl_shift_tail<MODEL>(a, b, xp);
         for (int k = 0; k < a.N; k++) for (int i = 0; i < NX; i++) X[(size_t)k * NX + i] = X[(size_t)(k + 1) * NX + i];
         for (int k = 0; k + 1 < a.N; k++) for (int i = 0; i < NU; i++) U[(size_t)k * NU + i] = U[(size_t)(k + 1) * NU + i];
         for (int i = 0; i < NX; i++) X[(size_t)a.N * NX + i] = xp[i];
     }
+}
+// the same shift of ONE instance by one wave (k_cl_loop): the tail by lane 0, the copies by all lanes (read everything, then write)
+template <int MODEL>
+__device__ CLW_FN void cl_shift_wave(const ClArgs &a, int b, int lane) {
+    constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
+    double *X = a.Xn + (size_t)b * (a.N + 1) * NX, *U = a.Un + (size_t)b * a.N * NU;
+    double xp[NX];
+    if (lane == 0) cl_shift_tail<MODEL>(a, b, xp);
+    constexpr int PX = (64 * NX + 63) / 64, PU = (63 * NU + 63) / 64;      // N <= 64: elements per lane
+    double vx[PX], vu[PU];
+#pragma unroll
+    for (int i = 0; i < PX; i++) { const int o = lane + 64 * i; vx[i] = (o < a.N * NX) ? X[o + NX] : 0.0; }
+#pragma unroll
+    for (int i = 0; i < PU; i++) { const int o = lane + 64 * i; vu[i] = (o < (a.N - 1) * NU) ? U[o + NU] : 0.0; }
+    wla::wsync_mem();
+#pragma unroll
+    for (int i = 0; i < PX; i++) { const int o = lane + 64 * i; if (o < a.N * NX) X[o] = vx[i]; }
+#pragma unroll
+    for (int i = 0; i < PU; i++) { const int o = lane + 64 * i; if (o < (a.N - 1) * NU) U[o] = vu[i]; }
+    if (lane == 0) for (int i = 0; i < NX; i++) X[(size_t)a.N * NX + i] = xp[i];
+    wla::wsync_mem();
 }
 // nominal initialiser replacing the reference's IPOPT call for step 0: roll-out of the plant from x_meas under a
 // constant input; callers that have a better nominal pass it to slsqp_cl_init instead.

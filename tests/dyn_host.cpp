@@ -4,10 +4,10 @@
 using namespace dyn;
 template <int M> static void jac(const double *x, const double *u, double *A, double *B, double *f) {
     constexpr int NX = Dims<M>::NX, NU = Dims<M>::NU;
-    double col[NX], st[3 * NX];
-    ddyn_stages<M>(x, u, st, f);                 // the product's linearisation path: k_lin_val ...
+    double col[NX], st[3 * NX], tape[4 * NT_MAX];
+    ddyn_stages<M>(x, u, st, f, tape);           // the product's linearisation path: k_lin_val (stage points + the tape of transcendental values) ...
     for (int d = 0; d < NX + NU; d++) {
-        ddyn_tangent<M>(x, u, st, d, col);       // ... and k_lin_tan
+        ddyn_tangent<M>(x, u, st, tape, d, col); // ... and k_lin_tan (dual numbers, primal transcendentals replayed from the tape)
         for (int i = 0; i < NX; i++) { if (d < NX) A[i * NX + d] = col[i]; else B[i * NU + (d - NX)] = col[i]; }
     }
 }

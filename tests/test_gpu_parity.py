@@ -804,13 +804,16 @@ def test_fused_rti_chain_is_bitwise_the_separate_launches():
     assert t1["qp"] > 0 and t1["sweep"] > 0 and t0["qp"] > 0 and t0["sweep"] > 0               # both report a QP and a sweep time
 
 
-@pytest.mark.parametrize("budget_ms,cut_frac", [(0.3, 0.0), (3.0, 0.0), (1e6, 0.0), (0.0, 0.7)])
+@pytest.mark.parametrize("budget_ms,cut_frac", [(0.3, 0.0), (3.0, 0.0), (1e6, 0.0), (0.0, 0.7), (-1.0, 0.0), (-2.0, 0.0)])
 def test_decoupled_closed_loop_is_bitwise_the_step_by_step_loop(budget_ms, cut_frac):
     """slsqp_cl_run (instances advance through their MPC steps independently; a chain still running `budget_ms` after its launch started suspends
     itself between two block solves and resumes in the next round) against the step-by-step loop of slsqp_cl_step: per instance the same operations
     in the same order, so every logged array and every per-QP statistic is identical bit for bit -- whether nearly every solve is cut several
     times (0.3 ms), only the slow ones (3 ms), none (the budget never expires: rounds = steps), or the last 30 % of every round's chains (no time
-    limit, cut_frac 0.7).  Rocket from the script's x0, 96 seeds x 10 steps."""
+    limit, cut_frac 0.7).  budget_ms < 0 here stands for the PERSISTENT launch (opts.cl_persistent = 1, the default of the library: waves take
+    instances from a device-side FIFO and run whole MPC steps, linearisation and plant included, inside one kernel): -1 with as many waves as
+    instances, -2 with 7 waves for the 96 instances (SLSQP_LOOP_WAVES: every instance changes hands between waves ten times).
+    Rocket from the script's x0, 96 seeds x 10 steps."""
     from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
     m = get_model("rocket")
     N, B, steps = 20, 96, 10
@@ -828,7 +831,13 @@ def test_decoupled_closed_loop_is_bitwise_the_step_by_step_loop(budget_ms, cut_f
     ref_final = {k: cl.f.get(k, shp) for k, shp in (("x_meas", (m.nx,)), ("nominal_x", (N + 1, m.nx)), ("nominal_u", (N, m.nu)), ("primal_vec", (cl.f.n,)))}
     cl.close()
     cl = ClosedLoopMPC(m, N, B)
-    out = cl.run_decoupled(x0, steps, W, solve_nominal=True, continuation=2, budget_ms=budget_ms, cut_frac=cut_frac)
+    cl.f.opts.cl_persistent = 1 if budget_ms < 0 else 0
+    if budget_ms == -2.0:
+        os.environ["SLSQP_LOOP_WAVES"] = "7"
+    try:
+        out = cl.run_decoupled(x0, steps, W, solve_nominal=True, continuation=2, budget_ms=budget_ms, cut_frac=cut_frac)
+    finally:
+        os.environ.pop("SLSQP_LOOP_WAVES", None)
     fin = {k: cl.f.get(k, shp) for k, shp in (("x_meas", (m.nx,)), ("nominal_x", (N + 1, m.nx)), ("nominal_u", (N, m.nu)), ("primal_vec", (cl.f.n,)))}
     cl.close()
     for k in ("state_trajectory", "input_trajectory", "nominal_trajectory_x", "nominal_trajectory_u", "backoff_trajectory_x", "backoff_trajectory_u", "success",
@@ -837,7 +846,11 @@ def test_decoupled_closed_loop_is_bitwise_the_step_by_step_loop(budget_ms, cut_f
     for k in fin:
         assert np.array_equal(fin[k], ref_final[k], equal_nan=True), k
     assert np.array_equal(out["qp_stats"], np.stack(ref_stats, axis=1))
-    assert out["rounds"] == steps if budget_ms > 1e5 else out["rounds"] > steps, out["rounds"]
+    if budget_ms < 0:
+        ls = out["loop_stats"]
+        assert out["rounds"] == 1 and ls["mpc_steps"] == B * steps and ls["waves"] == (7 if budget_ms == -2.0 else B) and ls["busy_ms"] > 0, ls
+    else:
+        assert out["rounds"] == steps if budget_ms > 1e5 else out["rounds"] > steps, out["rounds"]
 
 
 def test_config5_shaped_monte_carlo_1024_seeds_30_steps():

@@ -49,15 +49,17 @@ def parse():
     ap.add_argument("--workload", default="closed_loop", choices=["closed_loop", "synthetic"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (synthetic step, single-slice roofline block)")
-    ap.add_argument("--slices", type=int, default=3, help="independent slices of the rank's batch, each with its own handle / HIP stream / host thread")
+    ap.add_argument("--slices", type=int, default=None, help="independent slices of the rank's batch, each with its own handle / HIP stream / host thread "
+                    "(default: 1 for the persistent launch, 3 otherwise)")
     ap.add_argument("--qp-eps", type=float, default=None, help="interior-point tolerance before the polish (default: the library's 1e-6)")
     ap.add_argument("--precision", type=int, default=0, help="0: fp64 (headline); 1: mixed fp32 factorisation / fp64 residuals (secondary figure)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--x0-scale", type=float, default=None, help="closed loop: initial state = hover + s (script x0 - hover); default 1.0 = the script's own state "
                     "(the nominal initialiser then runs its two-stage continuation)")
-    ap.add_argument("--decoupled", type=int, default=1, help="1 (default): the timed closed loop runs through slsqp_cl_run -- every instance advances through its MPC steps "
-                    "independently, a chain of QP solves still running --round-budget-ms after its launch started suspends itself and resumes in the next round (rocket "
-                    "script setting only); 0: one slsqp_cl_step per step for the whole slice")
+    ap.add_argument("--decoupled", type=int, default=2, help="2 (default): the timed closed loop is ONE persistent launch of slsqp_cl_run (k_cl_loop: wavefronts take "
+                    "instances from a device-side FIFO and run one whole MPC step each time -- shift, linearisation, RTI chain, nominal update, plant); 1: slsqp_cl_run in "
+                    "rounds (a chain of QP solves still running --round-budget-ms after its launch started suspends itself and resumes in the next round); both for the "
+                    "rocket script's setting only; 0: one slsqp_cl_step per step for the whole slice")
     ap.add_argument("--round-budget-ms", type=float, default=8.0)
     ap.add_argument("--round-cut-frac", type=float, default=0.0, help="a round's unfinished chains also suspend once this fraction of its participants are done (0: off)")
     ap.add_argument("--secondary-synthetic", action="store_true", help="also time round 1's synthetic step as a secondary figure")
@@ -68,6 +70,8 @@ def parse():
         args.x0_scale = 1.0 if args.x0_scale is None else args.x0_scale
     if args.batch is None:
         args.batch = 4096
+    if args.slices is None:
+        args.slices = 1 if args.decoupled == 2 else 3
     return args
 
 
@@ -173,6 +177,7 @@ class ClosedLoopSlices:
         assert self.step_no == 0
         acc = [dict(jac=0.0, qp=0.0, sweep=0.0, total=0.0) for _ in self.cl]
         self.rounds = [0] * len(self.cl)
+        self.loop_stats = [None] * len(self.cl)
 
         def work(k):
             cl, W = self.cl[k], self.W[k]
@@ -180,6 +185,10 @@ class ClosedLoopSlices:
             rounds = C.c_int(0)
             L.check(f.lib.slsqp_cl_run(f.h, steps, C.c_void_p(W.data_ptr()), L.DEVICE, C.byref(f.opts), float(budget_ms), float(cut_frac), C.byref(rounds)))
             self.rounds[k] = rounds.value
+            if f.opts.cl_persistent:
+                st = (C.c_double * L.CL_RUN_STATS_LEN)()
+                L.check(f.lib.slsqp_cl_run_stats(f.h, st, L.CL_RUN_STATS_LEN))
+                self.loop_stats[k] = {"waves": int(st[0]), "busy_ms": float(st[1]), "mpc_steps": int(st[2]), "launch_ms": float(st[3])}
             t = f.timing_ms()
             for key in acc[k]:
                 acc[k][key] += t[key]
@@ -290,7 +299,7 @@ def qp_statistics(stats):
 def bench_command(args, n_slices, x0_scale):
     """What a PMC pass must have been taken on to describe this run (profiles/<round>/pmc_traffic*.json hold the same dict under "command")."""
     return {"model": args.model, "batch": args.batch, "steps": args.steps, "warmup": args.warmup, "slices": n_slices, "x0_scale": x0_scale,
-            "precision": args.precision, "workload": args.workload, "decoupled": int(bool(args.decoupled)), "round_budget_ms": args.round_budget_ms, "round_cut_frac": args.round_cut_frac}
+            "precision": args.precision, "workload": args.workload, "decoupled": int(args.decoupled), "round_budget_ms": args.round_budget_ms, "round_cut_frac": args.round_cut_frac}
 
 
 def read_traffic(fname, key, command):
@@ -407,6 +416,7 @@ def main():
                 setattr(f.opts, k, int(os.environ['QP_' + k.upper()]))
         f.opts.precision = args.precision
         f.opts.time_kernels = 1          # HIP events around every launch of the dominant kernel, on its own stream (roofline leg)
+        f.opts.cl_persistent = 1 if args.decoupled == 2 else 0
         if args.qp_eps is not None:
             f.opts.qp_eps = args.qp_eps
         if synthetic:
@@ -464,19 +474,24 @@ def main():
     if args.workload == "closed_loop":
         seeds = rank * B + np.arange(B)
         x0 = x0_of(x0_scale)
+        can_decouple = bool(args.decoupled) and args.precision == 0 and m.rti == 1 and m.fast_sls_rti_steps == 1 and int(os.environ.get("QP_FUSE_RTI", "1")) != 0
         if args.warmup > 0:
             # warm the code paths (kernel code objects, allocator, clocks, the gather) on a DISJOINT seed batch of the same size: the timed region
             # below is then closed-loop steps 0 .. steps-1 of the rank's own seeds whatever --warmup says
             wdev = ClosedLoopSlices(m, N, WARM_SEED0 + rank * B + np.arange(B), args.slices, args.warmup, local_rank, tune)
             wdev.setup(x0, cont)
-            wdev.run(args.warmup, collect_stats=False)
+            if can_decouple:
+                wdev.run_decoupled(args.warmup, args.round_budget_ms, args.round_cut_frac)      # the same launches as the timed region
+            else:
+                wdev.run(args.warmup, collect_stats=False)
             gather(torch.cat([wdev.fetch_device("x_meas", (m.nx,)), wdev.fetch_device("u0", (m.nu,))], dim=1))     # warm the gather path
             wdev.close()
         dev = ClosedLoopSlices(m, N, seeds, args.slices, args.steps, local_rank, tune)
         nlp = dev.setup(x0, cont)
         barrier()
         dev.kernel_timing()
-        decoupled = bool(args.decoupled) and args.precision == 0 and m.rti == 1 and m.fast_sls_rti_steps == 1 and int(os.environ.get("QP_FUSE_RTI", "1")) != 0
+        decoupled = can_decouple
+        persistent = decoupled and args.decoupled == 2
         t0 = time.perf_counter()
         acc = dev.run_decoupled(args.steps, args.round_budget_ms, args.round_cut_frac) if decoupled else dev.run(args.steps)
         gather(torch.cat([dev.fetch_device("x_meas", (m.nx,)), dev.fetch_device("u0", (m.nu,))], dim=1))
@@ -491,7 +506,10 @@ def main():
         workload += (f": per instance and step shift + reset, linearise, fast-SLS RTI ({m.rti * (m.fast_sls_rti_steps + 1)} QP solves + "
                      f"{m.rti * m.fast_sls_rti_steps} SLS sweep(s)), nominal update, plant + seeded noise; x0 = {x0_txt}, nominal from the GPU "
                      f"initialiser (untimed); timed steps = closed-loop steps 0..{args.steps - 1}; warm-up = {args.warmup} step(s) of a disjoint seed batch")
-        if decoupled:
+        if persistent:
+            workload += ("; the whole loop is ONE persistent launch (slsqp_cl_run, k_cl_loop): wavefronts take instances from a device-side FIFO and run one whole MPC step "
+                         "each time, so every instance advances independently")
+        elif decoupled:
             workload += (f"; the steps run through slsqp_cl_run: every instance advances independently, chains still running {args.round_budget_ms} ms after their launch "
                          f"started resume in the next round")
         per_step = [np.concatenate([dev.stats[k][s] for k in range(len(dev.cl))]) for s in range(args.steps)]
@@ -500,12 +518,15 @@ def main():
         step_ms = np.mean(np.array(dev.step_ms), axis=0)          # per closed-loop step: GPU ms of slsqp_cl_step, mean over the rank's slices (they run concurrently)
         extra_cfg = {"nominal_initialiser_converged_frac": float((nlp == 0).mean()), "mpc_step_success_frac_last_step": float(succ.mean()), "qp": qstat,
                      "linearise_ms_per_step": float(np.mean([a["jac"] for a in acc])) / args.steps,
-                     "rounds_per_slice": getattr(dev, "rounds", None), "round_budget_ms": args.round_budget_ms if decoupled else None,
+                     "rounds_per_slice": getattr(dev, "rounds", None), "round_budget_ms": args.round_budget_ms if (decoupled and not persistent) else None,
+                     "persistent_launch": ([dict(ls, wave_busy_frac=ls["busy_ms"] / max(1e-9, ls["waves"] * ls["launch_ms"]), ms_per_mpc_step_in_a_wave=ls["busy_ms"] / max(1, ls["mpc_steps"]))
+                                            for ls in dev.loop_stats] if persistent else None),
                      "per_step": {"slice_gpu_ms": [round(float(v), 3) for v in step_ms],
                                   "qp_solves_run": [int(((st[:, :, 6] != -1) & (st[:, :, 6] != 2)).sum()) for st in per_step],
                                   "note": "slice_gpu_ms: HIP-event time of one slice's slsqp_cl_step, mean over the slices of rank 0; slices overlap, so the sum "
                                           "over steps exceeds the wall time"}}
     else:
+        decoupled = persistent = False
         dev, batch = make_synth(args.slices, 1234 + rank)
         dev.run(max(1, args.warmup))
         gather(dev.fetch_device("primal_vec", (n_var,))[:, m.nx:m.nx + m.nu].contiguous())
@@ -552,19 +573,23 @@ def main():
                  and (decoupled or (B // max(1, n_sl)) * (N + 1) >= 3072)
                  and int(os.environ.get("SLSQP_FUSE_RTI", "1")) != 0)
         sls_sweeps = int(sum(int(np.isin(st_[:, 0, 6], (0, 4)).sum()) for st_ in per_step)) if fused else 0
-        dom_kernel = "k_rti_chain" if fused else "k_qp_solve"
+        dom_kernel = "k_cl_loop" if persistent else ("k_rti_chain" if fused else "k_qp_solve")
         rb = roof_block(k_ms, k_launches, inst_sweeps, fact_stages, qp_solves, sls_sweeps)
         # HBM traffic from PMC counters: attached only when the committed passes were taken on exactly this command
         command = bench_command(args, n_sl, x0_scale)
         traffic, tsrc = read_traffic("pmc_traffic.json", dom_kernel + "_bytes_per_launch", command)
         calls = (sum(dev.rounds) if getattr(dev, "rounds", None) else args.steps * n_sl)
         step_tf = (fact_stages * kf + 2.0 * inst_sweeps * N * ks + args.steps * B * sweep_flop) / dt / 1e12
-        out["roofline"] = dict({"bound": "mfma", "kernel": dom_kernel, "peak": 78.6, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": tsrc}, **rb)
+        if persistent:
+            rb["note_work"] = ("one launch = the whole closed loop; the flops counted are those of the QP solves and SLS sweeps only (the linearisation, nominal update and "
+                               "plant steps the kernel also runs are not counted)")
+        out["roofline"] = dict({"bound": "mfma", "kernel": dom_kernel, "peak": 78.6, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": tsrc, "command": command}, **rb)
         out["roofline"].update({
             "note": "fp64: matrix peak = vector peak on MI355X; the kernel issues its block products on the matrix core and is bound by vector-ALU issue",
-            "qp_solve": {"avg_ms": sum(a["qp"] for a in acc) / (qp_per_inst * calls), "instances": B / n_sl,
-                         "note": ("fused chain: (launch duration - the sweep part as instance 0 spent it in the kernel) / 2" if fused else "one solve call = one slice") +
-                                 "; slices run concurrently, so these times overlap"},
+            "qp_solve": (None if persistent else
+                         {"avg_ms": sum(a["qp"] for a in acc) / (qp_per_inst * calls), "instances": B / n_sl,
+                          "note": ("fused chain: (launch duration - the sweep part as instance 0 spent it in the kernel) / 2" if fused else "one solve call = one slice") +
+                                  "; slices run concurrently, so these times overlap"}),
             # the whole step: fp64 work of the timed region (QP kernel + 9.0 Mflop per rocket instance for the SLS sweep) over wall time
             "whole_step_fp64": {"achieved_TFLOPs": step_tf, "peak_TFLOPs": 78.6, "frac": step_tf / 78.6},
             "sweep_avg_launch_ms": (None if (args.workload == "closed_loop" and decoupled) else sum(a["sweep"] for a in acc) / calls), "slice_gpu_ms_per_step": [round(a["total"] / args.steps, 2) for a in acc]})
@@ -601,7 +626,8 @@ def main():
                 if args.workload == "closed_loop" and headline:
                     # round 2's headline regime as a labelled secondary figure: the same loop from the state scaled to 0.3 of its distance from hover,
                     # closed-loop steps 1..5 timed after step 0 (what profiles/r02/bench_line.json timed)
-                    sec = ClosedLoopSlices(m, N, seeds, args.slices, 6, local_rank, tune)
+                    sec_slices = 3
+                    sec = ClosedLoopSlices(m, N, seeds, sec_slices, 6, local_rank, tune)
                     sec.setup(x0_of(X0_SCALE_SECONDARY), 1)
                     sec.run(1, collect_stats=False)
                     torch.cuda.synchronize()
@@ -615,7 +641,7 @@ def main():
                     sec.close()
                     out["secondary"] = {"workload": f"round-2 headline regime: the same closed loop from hover + {X0_SCALE_SECONDARY} (script x0 - hover), closed-loop steps 1..5 "
                                                     "(few active bounds, no interior point)", "ms_per_step": 1e3 * dts, "qp_solves_per_s": qs_sec / (5 * dts), "steps": 5,
-                                        "slices": args.slices}
+                                        "slices": sec_slices, "loop": "one slsqp_cl_step per step and slice"}
             except Exception as e:
                 out["secondary"] = {"error": repr(e)}
             if args.secondary_synthetic:

@@ -701,7 +701,7 @@ __device__ __forceinline__ void solve_begin_wave(const SolveBeginArgs &a, int b,
 }
 struct LoopArgs {
     ChainArgs c; ClArgs cl; LinArgs lin; BoundsArgs ba; SolveBeginArgs sb; ClLogArgs lg; ScpArgs sa;
-    int steps, n, have_log, fence;
+    int steps, n, have_log, fence, keep_laggards;
     int *stepno; double *call_ids, *q; int *stale, *itnum, *pending, *scp_active;
     const double *W_all; double *pinf;
     ClQueue Q;
@@ -739,7 +739,7 @@ __device__ CLW_FN void cl_step_begin(const LoopArgs &L, int b, int lane) {
     wla::wsync_mem();
     CLSTAMP(6);
 }
-// nominal += delta, primal infeasibility, log entry, plant + noise, step counter; returns 1 while the instance has steps left
+// nominal += delta, primal infeasibility, log entry, plant + noise, step counter; returns the instance's new step count while it has steps left, else 0
 template <int MODEL>
 __device__ CLW_FN int cl_step_end(const LoopArgs &L, int b, int lane) {
     constexpr int NX = dyn::Dims<MODEL>::NX;
@@ -767,32 +767,60 @@ __device__ CLW_FN int cl_step_end(const LoopArgs &L, int b, int lane) {
     }
     wla::wsync_mem();
     CLSTAMP(10);
-    return (s + 1 < L.steps) ? 1 : 0;
+    return (s + 1 < L.steps) ? s + 1 : 0;
 }
 template <int MODEL>
 __global__ __launch_bounds__(64, QP_PERSIST_WAVES_PER_SIMD) void k_cl_loop(LoopArgs L) {
     constexpr int NX = dyn::Dims<MODEL>::NX, NU = dyn::Dims<MODEL>::NU;
     int lane = threadIdx.x;
     extern __shared__ double sm[];
+    int b = -1;
+#ifdef CL_LOOP_STAMP
+    const unsigned long long tw0_ = wall_clock64();
+    if (lane == 0) atomicMin(L.busy + 14, tw0_);
+#endif
 #pragma unroll 1
     for (;;) {
         asm volatile("" : "+v"(lane));
-        int b = clq_pop(L.Q, lane);
-        if (b < 0) break;
-        if (L.fence & 1) __threadfence();      // acquire: what the wave that ran this instance's previous step wrote (possibly through another XCD's L2)
+        if (b < 0) {
+#ifdef CL_LOOP_STAMP
+            const unsigned long long tp_ = wall_clock64();
+#endif
+            b = clq_pop(L.Q, lane);
+            if (b < 0) break;
+            if (L.fence & 1) __threadfence();      // acquire: what the wave that ran this instance's previous step wrote (possibly through another XCD's L2)
+#ifdef CL_LOOP_STAMP
+            if (lane == 0) atomicAdd(L.busy + 11, wall_clock64() - tp_);
+#endif
+        }
         cl_step_begin<MODEL>(L, b, lane);
         b = __builtin_amdgcn_readfirstlane(b);      // (across a call the compiler may park it in a vector register)
         asm volatile("" : "+v"(lane));
         rti_chain_dev<NX, NU>(L.c, b, lane, sm);
         wla::wsync_mem();
         asm volatile("" : "+v"(lane));
-        const int more = __builtin_amdgcn_readfirstlane(cl_step_end<MODEL>(L, b, lane));
+        const int next = __builtin_amdgcn_readfirstlane(cl_step_end<MODEL>(L, b, lane));
         b = __builtin_amdgcn_readfirstlane(b);
-        if (more) {
-            if (L.fence & 2) __threadfence();      // release: the next step of this instance may run anywhere
-            clq_push(L.Q, b, lane);
-        }
+        if (!next) { b = -1; continue; }
+        // An instance that is behind the batch's mean progress keeps its wave and goes straight on (a few instances are slow in MANY of their
+        // steps: queueing after each of them they would finish long after the others, with the GPU nearly empty); the others queue up, so the
+        // waves are shared fairly among the instances that are level
+        const unsigned long long done_steps = __hip_atomic_load(L.busy + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int behind = __builtin_amdgcn_readfirstlane(((unsigned long long)next * (unsigned long long)L.cl.B < done_steps) ? 1 : 0);
+        if (behind && L.keep_laggards) continue;
+#ifdef CL_LOOP_STAMP
+        const unsigned long long tq_ = wall_clock64();
+#endif
+        if (L.fence & 2) __threadfence();      // release: the next step of this instance may run anywhere
+        clq_push(L.Q, b, lane);
+        b = -1;
+#ifdef CL_LOOP_STAMP
+        if (lane == 0) atomicAdd(L.busy + 12, wall_clock64() - tq_);
+#endif
     }
+#ifdef CL_LOOP_STAMP
+    if (lane == 0) { const unsigned long long te_ = wall_clock64(); atomicAdd(L.busy + 13, te_ - tw0_); atomicMax(L.busy + 15, te_); atomicAdd(L.busy + 1, 1ULL); }
+#endif
 }
 
 // ---- masked pieces of a closed-loop round (slsqp_cl_run) ----
@@ -1531,6 +1559,7 @@ static int cl_run_persistent(slsqp_handle *h, int steps, const double *dW, const
                      h->pinf, h->lg_x, h->lg_u, h->lg_bx, h->lg_bu, h->lg_state, h->lg_u0, h->lg_pinf, h->lg_succ, h->lg_it};
     L.sa = ScpArgs{0, 0, o.scp_eps, h->scp_active, h->scp_success, h->scp_iters, h->counter + 2, h->scp_dmax, h->scp_upd};
     L.steps = steps; L.n = h->n; L.have_log = h->log_steps > 0 ? 1 : 0;
+    L.keep_laggards = getenv("SLSQP_LOOP_KEEP") ? atoi(getenv("SLSQP_LOOP_KEEP")) : 1;
     L.fence = getenv("SLSQP_LOOP_FENCE") ? atoi(getenv("SLSQP_LOOP_FENCE")) : 3;      // (experiments only: 0 drops the hand-over fences)
     L.stepno = h->cl_stepno; L.call_ids = h->call_ids; L.q = h->q; L.stale = h->stale; L.itnum = h->itnum; L.pending = h->pending_reset; L.scp_active = h->scp_active;
     L.W_all = dW; L.pinf = h->pinf;
@@ -1538,6 +1567,7 @@ static int cl_run_persistent(slsqp_handle *h, int steps, const double *dW, const
     L.busy = h->cl_busy; L.t_begin = h->cl_tbegin;
     hipLaunchKernelGGL(k_clq_init, dim3(64), dim3(256), 0, h->st, B, L.Q);
     HIPCHK(hipMemsetAsync(h->cl_busy, 0, 16 * sizeof(unsigned long long), h->st));
+    HIPCHK(hipMemsetAsync(h->cl_busy + 14, 0xFF, sizeof(unsigned long long), h->st));      // (CL_LOOP_STAMP builds: earliest wave start)
     HIPCHK(hipMemsetAsync(h->counter + 2, 0, sizeof(int), h->st));
     const int tl_tot = tl_begin(h, 2), tl_c = tl_begin(h, 4);
     int rc = -1;
@@ -1570,7 +1600,8 @@ static int cl_run_persistent(slsqp_handle *h, int steps, const double *dW, const
 extern "C" int slsqp_cl_run_stats(slsqp_handle *h, double *out, int len) {
     if (!out || len < SLSQP_CL_RUN_STATS_LEN) return fail("slsqp_cl_run_stats: the buffer must hold SLSQP_CL_RUN_STATS_LEN (4) doubles");
     out[0] = (double)h->cl_loop_waves; out[1] = (double)h->cl_busy_host[0] * 1e-5; out[2] = (double)h->cl_busy_host[2]; out[3] = h->cl_loop_ms;
-    for (int i = 4; i < 16 && i < len; i++) out[i] = (double)h->cl_busy_host[i] * 1e-5;      // -DCL_LOOP_STAMP builds: ms spent in the parts of the step around the chain
+    for (int i = 4; i < 16 && i < len; i++) out[i] = (double)h->cl_busy_host[i] * 1e-5;
+    if (len >= 16) { out[14] = (double)(h->cl_busy_host[15] - h->cl_busy_host[14]) * 1e-5; out[15] = (double)h->cl_busy_host[1]; }      // first wave start -> last wave exit; waves that ran      // -DCL_LOOP_STAMP builds: ms spent in the parts of the step around the chain
     return 0;
 }
 

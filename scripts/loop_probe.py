@@ -34,6 +34,8 @@ for w in waves:
     if sum(st[4:11]) > 0:
         names = ["shift+reset", "linearise", "x0/solve_begin", "scp_update", "infeas", "log", "plant"]
         print("   parts per MPC step (ms): " + ", ".join(f"{nm} {st[4 + i] / max(1, ls['mpc_steps']):.3f}" for i, nm in enumerate(names)))
+        print(f"   waves that ran {int(st[15])}; first wave start -> last wave exit {st[14]:.2f} ms; mean wave life time {st[13] / max(1.0, st[15]):.2f} ms; per wave: in steps {ls['busy_ms'] / max(1.0, st[15]):.2f}, "
+              f"pop + acquire {st[11] / max(1.0, st[15]):.2f}, release + push {st[12] / max(1.0, st[15]):.2f} ms")
     print(f"waves {ls['waves']:5d}: launch {ls['launch_ms']:8.2f} ms = {ls['launch_ms'] / steps:6.2f} ms/step | per MPC step in a wave {ls['busy_ms'] / max(1, ls['mpc_steps']):6.3f} ms | "
           f"waves busy {ls['busy_ms'] / (ls['waves'] * ls['launch_ms']):5.3f} | success {out['success'].mean():.4f} (wall incl. nominal initialiser {wall:.2f} s)", flush=True)
 cl.close()

@@ -26,6 +26,6 @@ for k, v in acc.items():
         d["mfma_busy_cycles_per_sq_busy_cycle"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / bc
     out[k] = d
 json.dump({"source": "rocprofv3 --pmc (one SQ pass), command: " + cmd, "kernels": out}, open(dst, "w"), indent=1)
-for k in ("k_rti_chain", "k_qp_solve", "k_sweep_prop", "k_sweep_ric1", "k_lin_tan", "k_lin_val"):
+for k in ("k_cl_loop", "k_rti_chain", "k_qp_solve", "k_sweep_prop", "k_sweep_ric1", "k_lin_tan", "k_lin_val"):
     if k in out:
         print(k, {a: (round(b, 4) if isinstance(b, float) and b < 10 else b) for a, b in out[k].items()})

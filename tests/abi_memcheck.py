@@ -77,6 +77,13 @@ for i in range(steps):
     cl.step(W[i])
 res = cl.run(np.tile(m.extra["x0"], (4, 1)), steps, W)
 res_dev = cl.run_on_device(np.tile(m.extra["x0"], (4, 1)), steps, W)
+# the whole loop as one persistent launch (slsqp_cl_run: rti = 1 loops only) and its statistics; a short statistics buffer is refused untouched
+cl.rti = 1
+cl.f.set_rti_steps(1)
+res_run = cl.run_decoupled(np.tile(m.extra["x0"], (4, 1)), steps, W)
+assert res_run["rounds"] == 1 and res_run["loop_stats"]["mpc_steps"] == 4 * steps
+short = (C.c_double * 8)(*([-7.0] * 8))
+assert cl.f.lib.slsqp_cl_run_stats(cl.f.h, short, 3) != 0 and b"SLSQP_CL_RUN_STATS_LEN" in cl.f.lib.slsqp_last_error() and list(short) == [-7.0] * 8
 cl.save_npz(os.path.join(os.environ.get("TMPDIR", "/tmp"), "abi_memcheck.npz"), res, 0)
 cl.close()
 print("abi_memcheck ok")

@@ -271,7 +271,8 @@ class _FakeSlices:
         return [dict(jac=0.1 * steps, qp=0.5 * steps, sweep=0.2 * steps, total=1.0 * steps) for _ in self.cl]
 
     def run_decoupled(self, steps, budget_ms, cut_frac=0.0):
-        self.rounds = [steps + 2] * len(self.cl)
+        self.rounds = [1] * len(self.cl)      # the persistent launch: no rounds
+        self.loop_stats = [dict(waves=c.B, busy_ms=0.8 * steps * c.B, mpc_steps=steps * c.B, launch_ms=1.0 * steps) for c in self.cl]
         return self.run(steps)
 
     def fetch_run_stats(self, steps):
@@ -336,6 +337,8 @@ def test_bench_multi_rank_path_world_size_2_gloo():
     assert line["config"]["qp_solves_nominal"] == 96 and abs(line["value"] * line["ms_per_step"] * 3e-3 - 96) < 1e-6
     assert "closed-loop steps 0..2" in line["config"]["workload"] and "disjoint seed batch" in line["config"]["workload"]
     assert line["roofline"]["traffic"] is None and line["cpu_baseline"] is None
+    assert line["roofline"]["kernel"] == "k_cl_loop" and line["config"]["slices_per_gpu"] == 1 and "ONE persistent launch" in line["config"]["workload"]
+    assert abs(line["config"]["persistent_launch"][0]["wave_busy_frac"] - 0.8) < 1e-12
     for rank, _, gathered in res:
         warm, timed = gathered[0], gathered[-1]
         assert len(timed) == 2 and np.array_equal(timed[0][:, 0], np.arange(8.0)) and np.array_equal(timed[1][:, 0], 8.0 + np.arange(8.0))
@@ -430,7 +433,7 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
     for st, names in fields.items():
         src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
         src += [f'  printf("{st}.{n} %zu\\n", offsetof({st}, {n}));' for n in names]
-    src += ['  printf("SLSQP_TIMING_LEN %d\\n", SLSQP_TIMING_LEN);', '  printf("SLSQP_KERNEL_TIMING_LEN %d\\n", SLSQP_KERNEL_TIMING_LEN);']
+    src += ['  printf("SLSQP_TIMING_LEN %d\\n", SLSQP_TIMING_LEN);', '  printf("SLSQP_KERNEL_TIMING_LEN %d\\n", SLSQP_KERNEL_TIMING_LEN);', '  printf("SLSQP_CL_RUN_STATS_LEN %d\\n", SLSQP_CL_RUN_STATS_LEN);']
     src += ['  return 0;', '}']
     cfile = tmp_path / "layout.c"
     cfile.write_text("\n".join(src))
@@ -439,7 +442,7 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
     got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
     assert int(got["slsqp_opts"]) == C.sizeof(L.Opts) and int(got["slsqp_dims"]) == C.sizeof(L.Dims)
     # buffer lengths of the two timing queries (the library refuses shorter buffers; the mirror sizes its own from these)
-    assert int(got["SLSQP_TIMING_LEN"]) == L.TIMING_LEN and int(got["SLSQP_KERNEL_TIMING_LEN"]) == L.KERNEL_TIMING_LEN
+    assert int(got["SLSQP_TIMING_LEN"]) == L.TIMING_LEN and int(got["SLSQP_KERNEL_TIMING_LEN"]) == L.KERNEL_TIMING_LEN and int(got["SLSQP_CL_RUN_STATS_LEN"]) == L.CL_RUN_STATS_LEN
     for cls, st in ((L.Opts, "slsqp_opts"), (L.Dims, "slsqp_dims")):
         for n in fields[st]:
             assert int(got[f"{st}.{n}"]) == getattr(cls, n).offset, (st, n)

@@ -70,8 +70,6 @@ def parse():
         args.x0_scale = 1.0 if args.x0_scale is None else args.x0_scale
     if args.batch is None:
         args.batch = 4096
-    if args.slices is None:
-        args.slices = 1 if args.decoupled == 2 else 3
     return args
 
 
@@ -475,6 +473,8 @@ def main():
         seeds = rank * B + np.arange(B)
         x0 = x0_of(x0_scale)
         can_decouple = bool(args.decoupled) and args.precision == 0 and m.rti == 1 and m.fast_sls_rti_steps == 1 and int(os.environ.get("QP_FUSE_RTI", "1")) != 0
+        if args.slices is None:      # the persistent launch takes the rank's whole batch; every other loop runs three free-running slices
+            args.slices = 1 if (can_decouple and args.decoupled == 2) else 3
         if args.warmup > 0:
             # warm the code paths (kernel code objects, allocator, clocks, the gather) on a DISJOINT seed batch of the same size: the timed region
             # below is then closed-loop steps 0 .. steps-1 of the rank's own seeds whatever --warmup says
@@ -527,6 +527,7 @@ def main():
                                           "over steps exceeds the wall time"}}
     else:
         decoupled = persistent = False
+        args.slices = 3 if args.slices is None else args.slices
         dev, batch = make_synth(args.slices, 1234 + rank)
         dev.run(max(1, args.warmup))
         gather(dev.fetch_device("primal_vec", (n_var,))[:, m.nx:m.nx + m.nu].contiguous())

@@ -598,9 +598,9 @@ __device__ __forceinline__ int rti_chain_dev(const ChainArgs &c, int b, int lane
             sweep_ric1_dev<NX, NU>(c.sw, b, lane, sm);
             wla::wsync_mem();
 #pragma unroll 1
-            for (int j = 0; j <= c.sw.s.N; j++) {
+            for (int j = 0; j <= c.sw.s.N; j += 2) {      // two disturbance columns per pass
                 asm volatile("" : "+v"(lane));
-                sweep_prop_dev<NX, NU>(c.sw, b, j, lane, sm);
+                sweep_prop_dev<NX, NU>(c.sw, b, j, min(2, c.sw.s.N + 1 - j), lane, sm);
                 wla::wsync();
             }
             wla::wsync_mem();
@@ -982,7 +982,7 @@ static int launch_sweep_shared_t(slsqp_handle *h, const SweepArgs &a) {
     SweepSharedArgs aa{a, h->Kc, h->Aclc, h->stale};
     const size_t lds_ric = sizeof(double) * sweep_lds_doubles<NX, NU>(), lds_prop = sizeof(double) * sweep_prop_lds_doubles<NX, NU>();
     hipLaunchKernelGGL((k_sweep_ric1<NX, NU>), dim3(h->B), dim3(64), lds_ric, h->st, aa);
-    hipLaunchKernelGGL((k_sweep_prop<NX, NU>), dim3(h->B * (h->d.N + 1)), dim3(64), lds_prop, h->st, aa);
+    hipLaunchKernelGGL((k_sweep_prop<NX, NU>), dim3(h->B * ((h->d.N + 2) / 2)), dim3(64), lds_prop, h->st, aa);      // one wave per pair of disturbance columns
     HIPCHK(hipGetLastError());
     return 0;
 }

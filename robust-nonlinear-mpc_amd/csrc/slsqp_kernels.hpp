@@ -1966,27 +1966,33 @@ __global__ __launch_bounds__(64, SWEEP_WAVES_PER_SIMD) void k_sweep_ric1(SweepSh
 }
 
 template <int NX, int NU>
-__host__ __device__ constexpr int sweep_prop_lds_doubles() { return 3 * NX * NX + 2 * NX * NU + 8; }
+__host__ __device__ constexpr int sweep_prop_lds_doubles() { return 5 * NX * NX + 3 * NX * NU + 8; }
 
+// Phi propagation of TWO disturbance columns j0, j0 + 1 (ncols = 1: only j0) of one instance by one wave: per stage K_k and A_k + B_k K_k go to LDS
+// once and serve both columns, whose products are independent chains on the matrix core (the wave waits on dependent LDS -> MFMA -> LDS round trips;
+// with two columns every such trip carries twice the work).  Column j0 + 1 starts one stage later.  Per column the arithmetic is that of a wave
+// that propagates it alone.
 template <int NX, int NU>
-__device__ __forceinline__ void sweep_prop_dev(const SweepSharedArgs &aa, int b, int j, int lane, double *sm) {
+__device__ __forceinline__ void sweep_prop_dev(const SweepSharedArgs &aa, int b, int j0, int ncols, int lane, double *sm) {
     const SweepArgs &a = aa.s;
     using L = Lay<NX, NU>;
     constexpr int NZ = L::NZ, NI = L::NI, NIF = L::NIF, NW = NX;
     const int N = a.N;
     double *p = sm;
-    double *sAcl = p; p += NX * NX; double *sPhi = p; p += NX * NX; double *sPhi2 = p; p += NX * NX;
-    double *sK = p; p += NX * NU; double *sPu = p; p += NU * NW;
+    double *sAcl = p; p += NX * NX;
+    double *PcA = p; p += NX * NX; double *PnA = p; p += NX * NX;
+    double *PcB = p; p += NX * NX; double *PnB = p; p += NX * NX;
+    double *sK = p; p += NX * NU; double *sPuA = p; p += NU * NW; double *sPuB = p; p += NU * NW;
     const double *gKc = aa.Kc + (size_t)b * N * NU * NX, *gAc = aa.Aclc + (size_t)b * N * NX * NX;
     double *beta = a.beta + (size_t)b * N * N * NI, *beta_f = a.beta_f + (size_t)b * (N + 1) * NIF;
-    const double *Eg = a.E + (a.E_per_instance ? (size_t)b * (N + 1) * NX * NW : 0) + (size_t)j * NX * NW;
+    const double *EgA = a.E + (a.E_per_instance ? (size_t)b * (N + 1) * NX * NW : 0) + (size_t)j0 * NX * NW;
+    const bool two = ncols > 1;
 #pragma unroll
-    for (int o = lane; o < NX * NW; o += 64) sPhi[o] = Eg[o];
+    for (int o = lane; o < NX * NW; o += 64) { PcA[o] = EgA[o]; if (two) PcB[o] = EgA[NX * NW + o]; }
     wla::wsync();
-    double *Pc = sPhi, *Pn = sPhi2;
     constexpr int RA = (NX * NX + 63) / 64, RB = (NX * NU + 63) / 64;
     double rA[RA], rK[RB];
-    double ctube = 0.0;
+    double ctA = 0.0, ctB = 0.0;
     auto fetch2 = [&](int k) {
         const double *Ak = gAc + (size_t)k * NX * NX, *Kk = gKc + (size_t)k * NU * NX;
 #pragma unroll
@@ -1994,72 +2000,89 @@ __device__ __forceinline__ void sweep_prop_dev(const SweepSharedArgs &aa, int b,
 #pragma unroll
         for (int r = 0; r < RB; r++) rK[r] = Kk[min(r * 64 + lane, NX * NU - 1)];
     };
-    if (j < N) fetch2(j);
-    for (int k = j; k < N; k++) {
+    // row norms of [Phi_x; Phi_u] of column j at stage k -> beta, tube cost
+    auto norms = [&](const double *Pc, const double *sPu, int k, int j, double &ctube) {
+        const int g3 = lane / NZ, rw = lane - g3 * NZ;
+        const double *row = (rw < NX) ? Pc + rw * NW : sPu + (rw - NX) * NW;
+        double s = 0.0;
+        if (g3 < 3) {
+#pragma unroll
+            for (int q = 0; q < (NW + 2) / 3; q++) { const int w = 3 * q + g3; if (w < NW) s = fma(row[w], row[w], s); }
+        }
+        s = s + __shfl(s, lane + NZ) + __shfl(s, lane + 2 * NZ);
+        if (lane < NZ) {
+            const double wr = (lane < NX) ? a.cst.Qregd[lane] : a.cst.Rregd[lane - NX];
+            ctube = fma(wr * wr, s, ctube);
+            s = fmax(s, a.eps);
+            double *bo = beta + ((size_t)k * N + j) * NI;
+            bo[lane] = s; bo[NZ + lane] = s;
+        }
+    };
+    constexpr bool PAIR = (SWEEP_MFMA != 0) && NX >= 13;
+    if (j0 < N) fetch2(j0);
+    for (int k = j0; k < N; k++) {
 #pragma unroll
         for (int r = 0; r < RA; r++) { const int o = r * 64 + lane; if (o < NX * NX) sAcl[o] = rA[r]; }
 #pragma unroll
         for (int r = 0; r < RB; r++) { const int o = r * 64 + lane; if (o < NX * NU) sK[o] = rK[r]; }
         wla::wsync();
         if (k + 1 < N) fetch2(k + 1);
+        const bool bB = two && k > j0;      // column j0 + 1 has its first stage at k = j0 + 1
         // Phi_u = K Phi_x and Phi_{k+1} = (A + B K) Phi_k: on the matrix core both at once (independent MFMA chains, Phi_k's operand read once)
-        constexpr bool PAIR = (SWEEP_MFMA != 0) && NX >= 13;
-        if constexpr (PAIR) wla::gemm_mfma_pair<NU, NX, NW, NX>(sK, NX, sAcl, NX, Pc, NW, sPu, NW, Pn, NW, lane);
-        else wla::gemm_blk<NU, NW, NX, false, false, 1, 2, false>(sK, NX, Pc, NW, sPu, NW, 1.0, lane);  // Phi_u = K Phi_x
-        wla::wsync();
-        {
-            const int g3 = lane / NZ, rw = lane - g3 * NZ;
-            const double *row = (rw < NX) ? Pc + rw * NW : sPu + (rw - NX) * NW;
-            double s = 0.0;
-            if (g3 < 3) {
-#pragma unroll
-                for (int q = 0; q < (NW + 2) / 3; q++) { const int w = 3 * q + g3; if (w < NW) s = fma(row[w], row[w], s); }
-            }
-            s = s + __shfl(s, lane + NZ) + __shfl(s, lane + 2 * NZ);
-            if (lane < NZ) {
-                const double wr = (lane < NX) ? a.cst.Qregd[lane] : a.cst.Rregd[lane - NX];
-                ctube = fma(wr * wr, s, ctube);
-                s = fmax(s, a.eps);
-                double *bo = beta + ((size_t)k * N + j) * NI;
-                bo[lane] = s; bo[NZ + lane] = s;
-            }
+        if constexpr (PAIR) {
+            wla::gemm_mfma_pair<NU, NX, NW, NX>(sK, NX, sAcl, NX, PcA, NW, sPuA, NW, PnA, NW, lane);
+            if (bB) wla::gemm_mfma_pair<NU, NX, NW, NX>(sK, NX, sAcl, NX, PcB, NW, sPuB, NW, PnB, NW, lane);
+        } else {
+            wla::gemm_blk<NU, NW, NX, false, false, 1, 2, false>(sK, NX, PcA, NW, sPuA, NW, 1.0, lane);  // Phi_u = K Phi_x
+            if (bB) wla::gemm_blk<NU, NW, NX, false, false, 1, 2, false>(sK, NX, PcB, NW, sPuB, NW, 1.0, lane);
         }
-        if constexpr (!PAIR) wla::gemm_blk<NX, NW, NX, false, false, 3, 2, false>(sAcl, NX, Pc, NW, Pn, NW, 1.0, lane);   // Phi_{k+1} = Acl Phi_k
         wla::wsync();
-        double *t = Pc; Pc = Pn; Pn = t;
+        norms(PcA, sPuA, k, j0, ctA);
+        if (bB) norms(PcB, sPuB, k, j0 + 1, ctB);
+        if constexpr (!PAIR) {
+            wla::gemm_blk<NX, NW, NX, false, false, 3, 2, false>(sAcl, NX, PcA, NW, PnA, NW, 1.0, lane);   // Phi_{k+1} = Acl Phi_k
+            if (bB) wla::gemm_blk<NX, NW, NX, false, false, 3, 2, false>(sAcl, NX, PcB, NW, PnB, NW, 1.0, lane);
+        }
+        wla::wsync();
+        { double *t = PcA; PcA = PnA; PnA = t; }
+        if (bB) { double *t = PcB; PcB = PnB; PnB = t; }
     }
-    if (lane < NX) {
-        const double *row = Pc + lane * NW;
-        double s = 0.0;
+    auto terminal = [&](const double *Pc, int j, double ctube) {
+        if (lane < NX) {
+            const double *row = Pc + lane * NW;
+            double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) s = fma(row[w], row[w], s);
-        ctube = fma(a.cst.Qregfd[lane] * a.cst.Qregfd[lane], s, ctube);
-        s = fmax(s, a.eps);
-        beta_f[j * NIF + lane] = s; beta_f[j * NIF + NX + lane] = s;
-    }
-    ctube = wla::wave_sum(ctube);
-    if (lane == 0 && a.ct_part) a.ct_part[(size_t)b * (N + 1) + j] = ctube;
+            for (int w = 0; w < NW; w++) s = fma(row[w], row[w], s);
+            ctube = fma(a.cst.Qregfd[lane] * a.cst.Qregfd[lane], s, ctube);
+            s = fmax(s, a.eps);
+            beta_f[j * NIF + lane] = s; beta_f[j * NIF + NX + lane] = s;
+        }
+        ctube = wla::wave_sum(ctube);
+        if (lane == 0 && a.ct_part) a.ct_part[(size_t)b * (N + 1) + j] = ctube;
+    };
+    terminal(PcA, j0, ctA);
+    if (two) terminal(PcB, j0 + 1, ctB);
 }
 template <int NX, int NU>
-__global__ __launch_bounds__(64, 4) void k_sweep_prop(SweepSharedArgs aa) {
+__global__ __launch_bounds__(64, 3) void k_sweep_prop(SweepSharedArgs aa) {
     const SweepArgs &a = aa.s;
-    const int ncol = a.N + 1;
-    int b, j;
-    {   // XCD-aware mapping: blocks i and i+8 share an XCD; all columns of an instance stay on one XCD (its K_k, A_k + B_k K_k stay in that L2)
+    const int ncol = a.N + 1, npair = (ncol + 1) / 2;
+    int b, jp;
+    {   // XCD-aware mapping: blocks i and i+8 share an XCD; all column pairs of an instance stay on one XCD (its K_k, A_k + B_k K_k stay in that L2)
         const int bid = blockIdx.x;
         const int Bfull = (a.B / 8) * 8;
-        if (bid < Bfull * ncol) {
+        if (bid < Bfull * npair) {
             const int xcd = bid % 8, slot = bid / 8;
-            b = (slot / ncol) * 8 + xcd; j = slot % ncol;
+            b = (slot / npair) * 8 + xcd; jp = slot % npair;
         } else {
-            const int r = bid - Bfull * ncol;
-            b = Bfull + r / ncol; j = r % ncol;
+            const int r = bid - Bfull * npair;
+            b = Bfull + r / npair; jp = r % npair;
         }
     }
     if (b >= a.B) return;
     if (a.run && !a.run[b]) return;
     extern __shared__ double sm[];
-    sweep_prop_dev<NX, NU>(aa, b, j, threadIdx.x, sm);
+    sweep_prop_dev<NX, NU>(aa, b, 2 * jp, min(2, ncol - 2 * jp), threadIdx.x, sm);
 }
 
 // ------------------------------------------------------------------------------------------------

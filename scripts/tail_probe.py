@@ -36,4 +36,12 @@ print("interior-point iterations when used: qp1 mean %.1f, qp2 mean %.1f" % (its
 # how much of a fallback solve is the failed first attempt?  rounds (index 5) counts active-set rounds of the attempt(s)
 rd = qs[..., 5].astype(float)
 print("fallback solves: active-set rounds mean qp1 %.1f qp2 %.1f" % (rd[..., 0][fb[..., 0] & ran[..., 0]].mean(), rd[..., 1][fb[..., 1] & ran[..., 1]].mean()))
+heavy = (blk > 40) & ran
+for slot in (0, 1):
+    hq = qs[:, :, slot, :][heavy[:, :, slot]]
+    if len(hq):
+        print(f"qp{slot + 1} solves with more than 40 block solves: {len(hq)}; block solves mean {hq[:, 1].mean():.1f}, interior-point iterations mean {hq[:, 0].mean():.1f} max {hq[:, 0].max()}, "
+              f"factorisations mean {hq[:, 2].mean():.1f}, active-set rounds mean {hq[:, 5].mean():.1f} max {hq[:, 5].max()}, status counts {np.bincount(np.clip(hq[:, 6], 0, 7), minlength=6).tolist()}, path counts {np.bincount(hq[:, 7] % 10, minlength=4).tolist()}")
+        for r in hq[np.argsort(-hq[:, 1])[:8]]:
+            print("     its %d blk %d fac %d nact %d warm %d rounds %d status %d path %d" % tuple(r))
 cl.close()

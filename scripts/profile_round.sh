@@ -24,6 +24,15 @@ for v in $variants; do
   done
   echo "variant $v passes done" >> $out/progress.log
 done
+if [ "${SEPARATE:-0}" = "1" ]; then
+  # the separate launches (k_qp_solve / k_after_qp / k_sweep_ric1 / k_sweep_prop / k_tighten / k_qp_solve per step and slice): per-kernel times of the sweep kernels
+  export SLSQP_FUSE_RTI=0
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_sep -o ssep -- $cmd --decoupled 0 > $out/stats_sep.log 2>&1 || echo "stats pass (separate launches) failed"
+  unset SLSQP_FUSE_RTI
+  f=$(ls $out/stats_sep/*kernel_stats.csv $out/stats_sep/*/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && cp $f $out/kernel_stats_separate_launches.csv
+  rm -rf $out/stats_sep
+fi
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/pmc_sq -o p -- $cmd > $out/pmc_sq.log 2>&1 || echo "sq pass failed"
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/pmc_lds -o p -- $cmd > $out/pmc_lds.log 2>&1 || echo "lds pass failed"
 echo "sq passes done" >> $out/progress.log

@@ -38,6 +38,17 @@ rd = qs[..., 5].astype(float)
 print("fallback solves: active-set rounds mean qp1 %.1f qp2 %.1f" % (rd[..., 0][fb[..., 0] & ran[..., 0]].mean(), rd[..., 1][fb[..., 1] & ran[..., 1]].mean()))
 heavy = (blk > 40) & ran
 for slot in (0, 1):
+    hv, r, f = heavy[:, :, slot], ran[:, :, slot], fb[:, :, slot]
+    ok = r[:, :-1] & r[:, 1:]
+    for nm, prev in (("heavy", hv[:, :-1]), ("fallback", f[:, :-1]), ("two fallbacks in a row", np.concatenate([np.zeros((B, 1), bool), f[:, :-2] & f[:, 1:-1]], axis=1))):
+        sel = ok & prev
+        if sel.any():
+            print(f"qp{slot + 1}: after a previous-step {nm} solve ({int(sel.sum())} cases): P(fallback) {f[:, 1:][sel].mean():.3f}, P(heavy) {hv[:, 1:][sel].mean():.3f}, block solves mean {blk[:, 1:, slot][sel].mean():.1f}; "
+                  f"of all heavy solves {int((hv[:, 1:] & sel).sum())} / {int(hv.sum())} follow one")
+    # same-step coupling: QP2 after a QP1 that fell back
+sel = ran[:, :, 0] & ran[:, :, 1] & fb[:, :, 0]
+print(f"qp2 in a step whose qp1 fell back ({int(sel.sum())} cases): P(fallback) {fb[:, :, 1][sel].mean():.3f}, block solves mean {blk[:, :, 1][sel].mean():.1f}")
+for slot in (0, 1):
     hq = qs[:, :, slot, :][heavy[:, :, slot]]
     if len(hq):
         print(f"qp{slot + 1} solves with more than 40 block solves: {len(hq)}; block solves mean {hq[:, 1].mean():.1f}, interior-point iterations mean {hq[:, 0].mean():.1f} max {hq[:, 0].max()}, "

@@ -853,6 +853,38 @@ def test_decoupled_closed_loop_is_bitwise_the_step_by_step_loop(budget_ms, cut_f
         assert out["rounds"] == steps if budget_ms > 1e5 else out["rounds"] > steps, out["rounds"]
 
 
+def test_persistent_launch_at_full_occupancy_is_bitwise_the_step_by_step_loop():
+    """The default regime of slsqp_cl_run: more instances (3500) than the GPU holds wavefronts of k_cl_loop (3072), so every wave serves several
+    instances through the device-side FIFO, instances change waves (and XCDs) between their MPC steps, and the ones behind the mean keep theirs --
+    against one slsqp_cl_step per step for the whole batch, bit for bit (logged trajectories, success flags, per-QP statistics).  Rocket from the
+    script's x0, 5 steps."""
+    from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
+    m = get_model("rocket")
+    N, B, steps = 20, 3500, 5
+    x0 = np.tile(m.extra["x0"], (B, 1))
+    W = np.stack([disturbance_stream(s, steps, m.nx) for s in range(B)], axis=1)
+    cl = ClosedLoopMPC(m, N, B)
+    L = __import__("robust_nonlinear_mpc_amd")._lib
+    assert L.load().slsqp_cl_log(cl.f.h, steps) == 0
+    cl.reset(x0, solve_nominal=True, continuation=2)
+    ref_stats = []
+    for i in range(steps):
+        cl.step(W[i], fetch=False)
+        ref_stats.append(cl.f.get("qp_stats", (2, 8), np.int32))
+    ref = cl._log_result(steps, np.zeros((steps, 1)), np.zeros((steps, 1)), np.zeros((steps, 1)))
+    cl.close()
+    cl = ClosedLoopMPC(m, N, B)
+    assert cl.f.opts.cl_persistent == 1      # the library's default
+    out = cl.run_decoupled(x0, steps, W, solve_nominal=True, continuation=2)
+    cl.close()
+    for k in ("state_trajectory", "input_trajectory", "nominal_trajectory_x", "nominal_trajectory_u", "backoff_trajectory_x", "backoff_trajectory_u", "success",
+              "scp_iterations", "primal_infeasibility"):
+        assert np.array_equal(out[k], ref[k], equal_nan=True), k
+    assert np.array_equal(out["qp_stats"], np.stack(ref_stats, axis=1))
+    ls = out["loop_stats"]
+    assert ls["mpc_steps"] == B * steps and ls["waves"] < B and out["rounds"] == 1, ls
+
+
 def test_config5_shaped_monte_carlo_1024_seeds_30_steps():
     """BASELINE config 5 at its per-GPU size: 1024 disturbance seeds x 30 closed-loop steps of the rocket (N = 20, script weights, rti = 1, one fast-SLS
     step) from the SCRIPT'S OWN initial state (main_rocket...:110-126; nominal by the GPU initialiser's two-stage continuation).  Properties at full size:

@@ -455,3 +455,16 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
         decl = [d for d in body.split(";") if re.search(r"\b(int|double)\b", d)]
         n_members = sum(len(d.split(",")) for d in decl)
         assert n_members == len(fields[st]), (st, n_members, len(fields[st]))
+
+
+@pytest.mark.parametrize("B,steps,workers,keep", [(97, 50, 13, 1), (97, 50, 13, 0), (8, 40, 32, 1), (300, 20, 3, 1), (1, 30, 5, 1)])
+def test_instance_queue_protocol_model_under_thread_sanitizer(tmp_path, B, steps, workers, keep):
+    """The protocol of k_cl_loop's device-side instance FIFO (clq_pop / clq_push in csrc/slsqp_api.hip: tail / head tickets, a count of published items,
+    workers that exit when the count is <= 0, an instance behind the mean keeps its worker) as a host model on std::atomic, one thread per wavefront,
+    under ThreadSanitizer: every instance runs exactly `steps` steps in order, every hand-over carries the previous step's writes (release on push, acquire
+    on pop), nothing is stranded when workers exit, no worker hangs -- with more workers than instances, fewer, and a single instance."""
+    import subprocess
+    exe = tmp_path / "queue_model"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-o", str(exe), os.path.join(ROOT, "tests", "queue_model.cpp")])
+    r = subprocess.run([str(exe), str(B), str(steps), str(workers), str(keep)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok") and "ThreadSanitizer" not in r.stderr, (r.stdout, r.stderr[-2000:])

@@ -937,7 +937,12 @@ static QpArgs make_qp_args(slsqp_handle *h, const int *run, const slsqp_opts *o,
     const bool mx = o->precision == 1;
     a.n_refine = mx ? 3 : 1;   // fp64: one refinement solve; its forward sweep measures the dynamics residual of the first solve (certificate)
     if (getenv("SLSQP_NREFINE")) a.n_refine = atoi(getenv("SLSQP_NREFINE"));
-    a.early_ctol = mx ? 1e-2 : 1e-6;
+    // tolerance (relative to max(1, |q|inf)) of the look at an un-refined active-set solve.  fp64: the un-refined solve is good to ~1e-11, so the look can
+    // use nearly the certificate's own 1e-9 -- with 1e-6 (rounds 1 and 2) violations and wrong-sign multipliers between 1e-9 and 1e-6 went unnoticed until
+    // the refined solve's certificate check, and each of those late corrections cost a refinement solve and a fresh factorisation: 9.2 / 11.0 block solves per
+    // QP of the rocket loop against 5.9 / 8.0 with 1e-8 (same certified fractions; the numpy prototype of the iteration needs 3.95 rounds, the GPU now 3.8 / 4.7)
+    a.early_ctol = mx ? 1e-2 : 1e-8;
+    if (!mx && getenv("SLSQP_EARLY_CTOL")) a.early_ctol = atof(getenv("SLSQP_EARLY_CTOL"));      // (experiments)
     return a;
 }
 

@@ -20,8 +20,8 @@ def _run_slice(model, N, seeds, steps, x0, device, noise, solve_nominal, continu
     W = np.stack([disturbance_stream(s, steps, model.nx) for s in seeds], axis=1) if noise else None   # (steps, B, nx)
     cl = ClosedLoopMPC(model, N, B, device=device)
     X0 = np.tile(np.asarray(x0, dtype=float), (B, 1))
-    if budget_ms is not None and cl.rti == 1 and model.fast_sls_rti_steps == 1:      # instances advance independently (slsqp_cl_run): same bits
-        out = cl.run_decoupled(X0, steps, W, solve_nominal=solve_nominal, continuation=continuation, budget_ms=budget_ms)
+    if budget_ms != 0 and cl.rti == 1 and model.fast_sls_rti_steps == 1:      # instances advance independently (slsqp_cl_run): same bits
+        out = cl.run_decoupled(X0, steps, W, solve_nominal=solve_nominal, continuation=continuation, budget_ms=8.0 if budget_ms is None else budget_ms)
     else:
         out = cl.run_on_device(X0, steps, W, solve_nominal=solve_nominal, continuation=continuation)
     if cl.nlp_status is not None:
@@ -32,8 +32,9 @@ def _run_slice(model, N, seeds, steps, x0, device, noise, solve_nominal, continu
 
 def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise=True, gather=True, solve_nominal=False, slices=1, continuation=1,
                     budget_ms=None):
-    """budget_ms (rocket setting only): run every slice's loop through slsqp_cl_run -- no instance waits for the slowest one of its step; results are
-    the same bit for bit.
+    """The rocket script's setting (rti = 1, one fast-SLS step) runs every slice's loop through slsqp_cl_run -- by default ONE persistent launch per slice in
+    which no instance waits for another (budget_ms only matters for the round-based variant, ClosedLoopMPC.f.opts.cl_persistent = 0); budget_ms = 0 runs
+    one slsqp_cl_step per step for the whole slice instead.  The results are the same bit for bit either way.
     slices > 1: the rank's seeds are cut into that many independent slices, each with its own handle (HIP stream) and host thread
     (as in fast_sls.SlicedDeviceBatch): results are bit-identical, the slices' solver tails overlap each other's bulk launches."""
     import threading
@@ -64,7 +65,7 @@ def run_monte_carlo(model, N, seeds, steps, x0, rank=0, world=1, device=0, noise
         raise err[0]
     out = {}
     for key, v in parts[0].items():
-        if key == "rounds":
+        if key in ("rounds", "loop_stats"):
             out[key] = [p[key] for p in parts]
         elif isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == cuts[0][1] - cuts[0][0] and key not in ("t_jac", "t_qp", "t_riccati"):
             out[key] = np.concatenate([p[key] for p in parts], axis=0)

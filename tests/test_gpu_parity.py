@@ -853,6 +853,31 @@ def test_decoupled_closed_loop_is_bitwise_the_step_by_step_loop(budget_ms, cut_f
         assert out["rounds"] == steps if budget_ms > 1e5 else out["rounds"] > steps, out["rounds"]
 
 
+@pytest.mark.parametrize("model,N,B,steps", [("pendulum", 10, 200, 12), ("quadrotor", 20, 150, 8)])
+def test_persistent_launch_of_the_other_plants_is_bitwise_the_step_by_step_loop(model, N, B, steps):
+    """k_cl_loop is instantiated per plant (its linearisation, plant step and warm-start shift are the plant's): pendulum (transcendental tape of 2 values per
+    ODE evaluation) and quadrotor (none) in the setting slsqp_cl_run accepts (rti = 1, one fast-SLS step) against one slsqp_cl_step per step, bit for bit."""
+    from robust_nonlinear_mpc_amd import ClosedLoopMPC, disturbance_stream, get_model
+    m = get_model(model)
+    x0 = np.tile(m.extra["x0"], (B, 1)) if "x0" in m.extra else np.tile(m.x_ref + 0.02 * (m.x_ub - m.x_lb), (B, 1))
+    W = np.stack([disturbance_stream(s, steps, m.nx) for s in range(B)], axis=1)
+    outs = []
+    for persistent in (0, 1):
+        cl = ClosedLoopMPC(m, N, B, rti=1)
+        cl.f.set_rti_steps(1)
+        if persistent:
+            out = cl.run_decoupled(x0, steps, W, solve_nominal=True)
+            assert out["rounds"] == 1 and out["loop_stats"]["mpc_steps"] == B * steps
+        else:
+            out = cl.run_on_device(x0, steps, W, solve_nominal=True)
+        outs.append(out)
+        cl.close()
+    for k in ("state_trajectory", "input_trajectory", "nominal_trajectory_x", "nominal_trajectory_u", "backoff_trajectory_x", "backoff_trajectory_u", "success",
+              "scp_iterations", "primal_infeasibility"):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    assert outs[0]["success"].mean() > 0.5
+
+
 def test_persistent_launch_at_full_occupancy_is_bitwise_the_step_by_step_loop():
     """The default regime of slsqp_cl_run: more instances (3500) than the GPU holds wavefronts of k_cl_loop (3072), so every wave serves several
     instances through the device-side FIFO, instances change waves (and XCDs) between their MPC steps, and the ones behind the mean keep theirs --
